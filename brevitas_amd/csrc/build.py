@@ -1,0 +1,84 @@
+"""Build libbvq.so (the C-ABI HIP library) in-tree for gfx950.
+
+    python -m brevitas_amd.csrc.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting brevitas_amd/libbvq.so is git-ignored but travels
+to the GPU box with the source snapshot.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(CSRC)
+ROOT = os.path.dirname(PKG)
+LIB = os.path.join(PKG, 'libbvq.so')
+OBJ_DIR = os.path.join(ROOT, 'build', 'bvq')
+
+SOURCES = ['bvq_common.hip', 'bvq_elementwise.hip', 'bvq_stats.hip', 'bvq_fakequant.hip']
+HEADERS = ['bvq_common.h', 'bvq_quant_math.h', os.path.join(ROOT, 'include', 'bvq.h')]
+
+# -ffp-contract=off: the reference rounds after every op; a contracted mul+add would not.
+# hipcc's default fp32 division is correctly rounded (no -ffast-math, no approximate reciprocal).
+FLAGS = [
+    '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math',
+    '-Wall', '-Wno-unused-function', '-Wno-sometimes-uninitialized', '-Wno-uninitialized',
+    '-Wno-unused-variable']
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found: brevitas_amd needs the ROCm toolchain to build libbvq.so')
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS + [os.path.abspath(__file__)]:
+        path = f if os.path.isabs(f) else os.path.join(CSRC, f)
+        with open(path, 'rb') as fh:
+            h.update(fh.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    stamp = os.path.join(OBJ_DIR, 'stamp')
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp):
+        with open(stamp) as fh:
+            if fh.read().strip() == dig:
+                return LIB
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJ_DIR, src.replace('.hip', '.o'))
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed on %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            print(r.stderr, flush=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB + '.tmp'] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    os.replace(LIB + '.tmp', LIB)
+    with open(stamp, 'w') as fh:
+        fh.write(dig)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

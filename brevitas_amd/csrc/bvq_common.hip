@@ -1,0 +1,75 @@
+// bvq_common.hip -- error reporting, tiling and library-level entry points.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "bvq_common.h"
+
+namespace bvq {
+
+static thread_local char g_err[512] = {0};
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return BVQ_ERR_LAUNCH;
+  }
+  return BVQ_OK;
+}
+
+int default_piece_chunks() {
+  // tunable for experiments only; the shipped default is what bench.py measures
+  static int v = [] {
+    const char* e = getenv("BVQ_PIECE_CHUNKS");
+    int n = e ? atoi(e) : 0;
+    return (n >= 1 && n <= 4096) ? n : 8;
+  }();
+  return v;
+}
+
+int pick_vec(int max_vec, int64_t rows, int64_t row_len, const void* const* ptrs, const int* elsizes,
+             int nptr) {
+  int vec = max_vec;
+  while (vec > 1) {
+    bool ok = (rows == 1) || (row_len % vec == 0);
+    for (int i = 0; ok && i < nptr; ++i) {
+      if (!ptrs[i]) continue;
+      int need = vec * elsizes[i];
+      if (need > 16) need = 16;
+      if (reinterpret_cast<uintptr_t>(ptrs[i]) % need != 0) ok = false;
+    }
+    if (ok) break;
+    vec >>= 1;
+  }
+  return vec;
+}
+
+Tiling make_tiling(int64_t rows, int64_t row_len, int32_t channels, int vec) {
+  Tiling t;
+  t.rows = rows;
+  t.row_len = row_len;
+  t.channels = channels;
+  int64_t piece = (int64_t)default_piece_chunks() * kWave * vec;
+  if (piece > row_len) {
+    // one piece per row; keep it a multiple of vec unless the row is the whole tensor's ragged end
+    piece = row_len > 0 ? row_len : 1;
+    piece = ((piece + vec - 1) / vec) * vec;
+  }
+  t.piece_len = piece;
+  t.ppr = row_len > 0 ? (row_len + piece - 1) / piece : 0;
+  t.units = rows * t.ppr;
+  return t;
+}
+
+}  // namespace bvq
+
+extern "C" int bvq_abi_version(void) { return BVQ_ABI_VERSION; }
+extern "C" const char* bvq_last_error(void) { return bvq::g_err; }

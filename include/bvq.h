@@ -1,0 +1,205 @@
+/*
+ * bvq.h -- C ABI of libbvq.so, the MI355X (gfx950) fake-quantization engine.
+ *
+ * This is the drop-in boundary for Brevitas' per-tensor / per-channel integer
+ * quant-dequant hot path.  Nothing like it exists in the reference (it has no
+ * native kernels besides 12 ATen-forwarding STE ops); every entry point below
+ * names the reference interface whose tensor math it replaces.  Paths are
+ * relative to the reference checkout, `B/` = `src/brevitas/`.
+ *
+ * Conventions
+ *   - plain C, no torch types: raw device pointers, int64 sizes, a hipStream_t
+ *     passed as void*.  The library owns no memory across calls: every output
+ *     and every workspace is allocated by the caller (B/ ownership model: each
+ *     op returns a fresh tensor from the host framework's allocator).
+ *   - all pointers are DEVICE pointers unless the name says `host`.
+ *   - every function is re-entrant, never synchronises the device, never
+ *     allocates, and only enqueues work on `stream` (autograd runs backward on
+ *     its own thread: B/ has no threads of its own, SURVEY 8b "Threading").
+ *   - return 0 on success, a negative bvq_status otherwise; the message for the
+ *     calling thread's last failure is bvq_last_error().  Never throws.
+ *   - a tensor is described as [outer, channels, inner] (row-major,
+ *     contiguous).  channels == 1 means per-tensor.  A weight [Cout,Cin,kh,kw]
+ *     quantized per output channel is (1, Cout, Cin*kh*kw); an NCHW activation
+ *     quantized per channel is (N, C, H*W) -- no permute copy is ever made
+ *     (the reference does permute().contiguous(), B/core/function_wrapper/shape.py:19-27).
+ */
+#ifndef BVQ_H_
+#define BVQ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BVQ_ABI_VERSION 1
+
+typedef void* bvq_stream_t; /* hipStream_t */
+
+typedef enum bvq_status {
+  BVQ_OK = 0,
+  BVQ_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, bad enum) */
+  BVQ_ERR_UNSUPPORTED = -2, /* dtype / layout combination not built */
+  BVQ_ERR_WORKSPACE = -3,   /* workspace too small */
+  BVQ_ERR_LAUNCH = -4       /* HIP reported a launch error */
+} bvq_status;
+
+/* element types of tensors ("dtype" is the storage/arithmetic type, not a precision claim) */
+typedef enum bvq_dtype { BVQ_F32 = 0, BVQ_BF16 = 1, BVQ_F16 = 2 } bvq_dtype;
+
+/* float_to_int_impl variants: B/core/function_wrapper/ops_ste.py:14-76 */
+typedef enum bvq_round_mode {
+  BVQ_ROUND = 0,         /* torch.round, half to even  (round_ste,  B/function/ops_ste.py:46-67)  */
+  BVQ_FLOOR = 1,         /* torch.floor                (floor_ste,  :94-115)                      */
+  BVQ_CEIL = 2,          /* torch.ceil                 (ceil_ste,   :70-91)                       */
+  BVQ_ROUND_TO_ZERO = 3, /* sign(x)*floor(|x|)         (B/function/ops.py:37-53)                  */
+  BVQ_DPU_ROUND = 4      /* DPU rounding               (B/function/ops.py:56-72)                  */
+} bvq_round_mode;
+
+/* elementwise ops of the STE namespace, forward math only
+ * (B/ops/autograd_ste_ops.py:37-382, B/csrc/autograd_ste_ops.cpp:14-194) */
+typedef enum bvq_unary_op {
+  BVQ_OP_ROUND = 0,
+  BVQ_OP_FLOOR = 1,
+  BVQ_OP_CEIL = 2,
+  BVQ_OP_ROUND_TO_ZERO = 3,
+  BVQ_OP_DPU_ROUND = 4,
+  BVQ_OP_BINARY_SIGN = 5,  /* (x>=0) - (x<0), +1 at 0   (B/function/ops.py:16-34) */
+  BVQ_OP_TERNARY_SIGN = 6, /* torch.sign                                          */
+  BVQ_OP_ABS = 7           /* torch.abs (forward of abs_binary_sign_grad)         */
+} bvq_unary_op;
+
+typedef enum bvq_stat_kind {
+  BVQ_STAT_ABSMAX = 0, /* out[c]      = max |x|              (AbsMax,    B/core/stats/stats_op.py:129-141) */
+  BVQ_STAT_MINMAX = 1  /* out[c]=max, out[channels+c]=min    (AbsMinMax, B/core/stats/stats_op.py:144-158) */
+} bvq_stat_kind;
+
+/* How a 0-dim (one element) scale / zero-point whose dtype is WIDER than the
+ * compute dtype enters the arithmetic.  torch's own kernels differ here:
+ *   OPMATH: the scalar keeps its float32 value (ATen CPU reduced-float scalar path);
+ *   CAST  : the scalar is first rounded to the compute dtype (ATen device kernels).
+ * Same-dtype operands and per-channel operands are unaffected. */
+typedef enum bvq_scalar_mode { BVQ_SCALAR_OPMATH = 0, BVQ_SCALAR_CAST = 1 } bvq_scalar_mode;
+
+/* output selection for bvq_fakequant_fwd */
+#define BVQ_OUT_DEQUANT 0 /* y = (clamp(round(x/s+zp)) - zp) * s   IntQuant.forward, B/core/quant/int_base.py:86-97 */
+#define BVQ_OUT_INT 1     /* y =  clamp(round(x/s+zp))             IntQuant.to_int,  B/core/quant/int_base.py:63-76 */
+
+/*
+ * Descriptor of one affine integer quantizer application.
+ * Replaces the argument set of IntQuant.forward(scale, zero_point, bit_width, x)
+ * (B/core/quant/int_base.py:86-97): bit_width only enters through
+ * qmin = min_int(signed, narrow_range, bit_width), qmax = max_int(...)
+ * (B/function/ops.py:132-191), computed on the host.
+ */
+typedef struct bvq_quant_desc {
+  int64_t outer;    /* x viewed as [outer, channels, inner], contiguous */
+  int64_t channels; /* 1 = per-tensor */
+  int64_t inner;
+  int32_t x_dtype;     /* dtype of x and of dx */
+  int32_t ct_dtype;    /* torch.result_type(x, scale): dtype of every intermediate, of y and of g */
+  int32_t scale_dtype; /* dtype of the scale buffer */
+  int32_t zp_dtype;    /* dtype of the zero-point buffer */
+  int32_t scale_per_channel; /* 0: one element, 1: `channels` elements */
+  int32_t zp_per_channel;    /* 0: one element, 1: `channels` elements */
+  float qmin;          /* integer clamp bounds, as floats (the reference keeps them as 0-dim float tensors) */
+  float qmax;
+  int32_t round_mode;  /* bvq_round_mode */
+  int32_t scalar_mode; /* bvq_scalar_mode */
+  int32_t clamp_ste;   /* backward only. 1: TensorClampSte (grad passes clipped elements, weights);
+                          0: TensorClamp (grad masked where clipped, activations). B/core/quant/int_base.py:53-54 */
+  int32_t out_kind;    /* forward only. BVQ_OUT_DEQUANT or BVQ_OUT_INT */
+} bvq_quant_desc;
+
+/* ---- library ------------------------------------------------------------------------------ */
+
+int bvq_abi_version(void);
+/* message of the calling thread's last failing call ("" if none) */
+const char* bvq_last_error(void);
+
+/* ---- elementwise STE namespace (seam 1) ----------------------------------------------------
+ * Forward math of torch.ops.autograd_ste_ops.<name>_impl / brevitas.ops.autograd_ste_ops.<name>_impl
+ * (registration B/csrc/autograd_ste_ops.cpp:258-271, aliases B/ops/autograd_ste_ops.py:385-431).
+ * The straight-through backward of these ops is the identity and needs no kernel. */
+
+/* y[i] = op(x[i]).  x may alias y (tensor_clamp_ste_-style in-place use). */
+int bvq_unary(int op, int dtype, const void* x, void* y, int64_t n, bvq_stream_t stream);
+
+/* torch.clamp(x, lo, hi) / torch.clamp_min(x, lo): scalar_clamp_ste_impl, scalar_clamp_min_ste_impl
+ * (B/ops/autograd_ste_ops.py:37-97).  Bounds are host doubles rounded to `dtype` like torch does.
+ * use_lo / use_hi select which bounds apply.  NaN propagates. */
+int bvq_scalar_clamp(int dtype, const void* x, void* y, int64_t n, double lo, int use_lo, double hi,
+                     int use_hi, bvq_stream_t stream);
+
+/* tensor_clamp(x, min_val, max_val) = where(x>max,max,x) then where(out<min,min,out)
+ * (B/function/ops.py:75-100; tensor_clamp_ste_impl forward, B/ops/autograd_ste_ops.py:100-128).
+ * lo / hi are device buffers of dtype `dtype`: one element each when bounds_full == 0
+ * (the hot path: 0-dim min_int/max_int), n elements each when bounds_full == 1. */
+int bvq_tensor_clamp(int dtype, const void* x, const void* lo, const void* hi, int bounds_full, void* y,
+                     int64_t n, bvq_stream_t stream);
+
+/* backward of the non-STE tensor_clamp w.r.t. x (autograd of the two torch.where):
+ * dx = (!(x>hi) && !(x<lo)) ? g : 0 */
+int bvq_tensor_clamp_bwd(int dtype, const void* g, const void* x, const void* lo, const void* hi,
+                         int bounds_full, void* dx, int64_t n, bvq_stream_t stream);
+
+/* backward of abs_binary_sign_grad (B/ops/autograd_ste_ops.py:356-382): dx = binary_sign(x) * g */
+int bvq_abs_binary_sign_grad_bwd(int dtype, const void* g, const void* x, void* dx, int64_t n,
+                                 bvq_stream_t stream);
+
+/* ---- statistics (seam 2: AbsMax / AbsMinMax) ------------------------------------------------ */
+
+/* bytes of scratch bvq_stats needs for this problem (0 is a valid answer) */
+int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer, int64_t channels, int64_t inner);
+
+/* Per-channel (or whole-tensor, channels == 1) statistic over the `outer` and `inner` axes of
+ * x[outer, channels, inner].  One streaming read of x, no permuted copy.
+ *   ABSMAX: out[c] = max |x|, NaN if any NaN (torch.max semantics)       -> `channels` elements
+ *   MINMAX: out[c] = max x ; out[channels + c] = min x, NaN-propagating  -> 2*`channels` elements
+ * out has dtype out_dtype: BVQ_F32 or the dtype of x (the values are exact in either). */
+int bvq_stats(int kind, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+              int out_dtype, void* out, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
+
+/* Backward of AbsMax w.r.t. x, as autograd derives it from torch.max(torch.abs(x)[, dim])
+ * (B/core/stats/stats_op.py:137-141):
+ *   channels == 1 (full reduction): every element with |x| == stat receives sgn(x) * (gstat / #ties);
+ *   channels  > 1 (max along a dim): the FIRST such element of each channel, in (outer, inner)
+ *                                    order, receives sgn(x) * gstat[c].
+ * mode_add == 0: dx is fully written (zeros elsewhere); mode_add == 1: the terms are added in place
+ * to an existing dx (used by the fused quantizer backward; one streaming read of x, no write pass).
+ * stat, gstat and dx have dtype `dtype`.  workspace: bvq_stats_workspace_bytes(ABSMAX,...) bytes. */
+int bvq_absmax_bwd(int dtype, const void* x, const void* stat, const void* gstat, void* dx,
+                   int64_t outer, int64_t channels, int64_t inner, int mode_add, void* workspace,
+                   int64_t workspace_bytes, bvq_stream_t stream);
+
+/* ---- fused affine quantize / dequantize (seam 2: IntQuant) ---------------------------------- */
+
+/* Forward: one read of x, one write of y.
+ *   t = x / scale ; t = t + zp ; t = round_mode(t) ; t = clamp(t, qmin, qmax) ;
+ *   y = (t - zp) * scale          (BVQ_OUT_DEQUANT)   or   y = t   (BVQ_OUT_INT)
+ * with every operation rounded to ct_dtype exactly where the reference's op chain rounds
+ * (B/core/quant/int_base.py:63-97).  codes (nullable, int32, same element count) receives the
+ * clamped integer codes. */
+int bvq_fakequant_fwd(const bvq_quant_desc* desc, const void* x, const void* scale, const void* zp,
+                      void* y, int32_t* codes, bvq_stream_t stream);
+
+/* bytes of scratch bvq_fakequant_bwd needs */
+int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* desc);
+
+/* Backward of the chain above, as autograd derives it:
+ *   dt = pass ? g*scale : 0      pass = clamp_ste || !(t_rounded > qmax || t_rounded < qmin)
+ *   dx = dt / scale                                              (dtype x_dtype)
+ *   dscale[c] = sum g*(t_clamped - zp)  -  sum dt * ((x/scale)/scale)     (float32, nullable)
+ *   dzp[c]    = sum dt - sum g*scale                                      (float32, nullable)
+ * One read of g, one read of x, one write of dx; the per-channel sums ride on the same reads and
+ * are combined in a fixed order (bit-reproducible run to run). */
+int bvq_fakequant_bwd(const bvq_quant_desc* desc, const void* g, const void* x, const void* scale,
+                      const void* zp, void* dx, float* dscale, float* dzp, void* workspace,
+                      int64_t workspace_bytes, bvq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BVQ_H_ */

@@ -1,0 +1,418 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE on CPU.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Runs only in the build container: it imports brevitas.core.* / brevitas.function.* from
+/root/reference/src (read-only).  `brevitas.inject` needs the third-party `dependencies` package,
+which is not installed; the hot path does not use it, so a bare namespace stub stands in for that
+parent package -- no reference file is modified or copied.  The named quantizers
+(Int8WeightPerChannelFloat, ...) cannot be imported for the same reason; their resolved module
+graphs are assembled by hand exactly as SURVEY 8a lists them.
+
+What is committed are the resulting .npz files (inputs + expected outputs, bf16/f16 stored as
+uint16 bit patterns) and this script.  All inputs come from torch.manual_seed(123456), the seed of
+the reference's own tests (tests/conftest.py:7).
+"""
+import json
+import os
+import sys
+import types
+
+REF = '/root/reference/src'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+stub = types.ModuleType('brevitas.inject')
+stub.__path__ = [os.path.join(REF, 'brevitas', 'inject')]
+sys.modules['brevitas.inject'] = stub
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import brevitas  # noqa: E402
+from brevitas.core.bit_width import BitWidthConst  # noqa: E402
+from brevitas.core.function_wrapper import (CeilSte, DPURoundSte, FloorSte, OverOutputChannelView,  # noqa: E402
+                                            OverTensorView, RoundSte, RoundToZeroSte, TensorClamp,
+                                            TensorClampSte)
+from brevitas.core.quant import IntQuant, RescalingIntQuant  # noqa: E402
+from brevitas.core.restrict_val import FloatRestrictValue  # noqa: E402
+from brevitas.core.scaling import (ConstScaling, IntScaling, ParameterFromRuntimeStatsScaling,  # noqa: E402
+                                   ParameterScaling, RuntimeStatsScaling, StatsFromParameterScaling)
+from brevitas.core.stats import AbsMax, AbsMinMax  # noqa: E402
+from brevitas.core.zero_point import ZeroZeroPoint  # noqa: E402
+from brevitas.function import ops as ref_ops  # noqa: E402
+from brevitas.function import ops_ste as ref_ste  # noqa: E402
+
+assert not brevitas.NATIVE_STE_BACKEND_LOADED
+
+DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}
+ROUND_IMPL = {'round': RoundSte, 'floor': FloorSte, 'ceil': CeilSte, 'rtz': RoundToZeroSte,
+              'dpu': DPURoundSte}
+
+
+def enc(t):
+    """torch tensor -> numpy (bf16/f16 as uint16 bit patterns, everything else as is)"""
+    t = t.detach().contiguous()
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.view(torch.int16).numpy().view(np.uint16).copy()
+    return t.numpy().copy()
+
+
+def dtname(t):
+    return {torch.float32: 'f32', torch.bfloat16: 'bf16', torch.float16: 'f16'}[t.dtype]
+
+
+class Store:
+    def __init__(self, name):
+        self.name = name
+        self.arrays = {}
+        self.meta = []
+
+    def case(self, meta, **tensors):
+        idx = len(self.meta)
+        m = dict(meta)
+        m['dtypes'] = {}
+        for k, v in tensors.items():
+            if v is None:
+                continue
+            self.arrays['c%d_%s' % (idx, k)] = enc(v)
+            m['dtypes'][k] = dtname(v) if v.dtype.is_floating_point else str(v.dtype)
+        self.meta.append(m)
+
+    def save(self):
+        path = os.path.join(HERE, self.name + '.npz')
+        np.savez_compressed(path, __meta__=np.frombuffer(json.dumps(self.meta).encode(), dtype=np.uint8),
+                            **self.arrays)
+        print('%s: %d cases, %.1f KB' % (path, len(self.meta), os.path.getsize(path) / 1024))
+
+
+def adversarial(dtype, n_rand=96):
+    """ties, signed zeros, denormals, range boundaries, inf/nan, plus seeded randoms"""
+    ties = torch.arange(-6, 7, dtype=torch.float32) + 0.5
+    special = torch.tensor([0.0, -0.0, 1e-40, -1e-40, 1.17549435e-38, 1e-10, -1e-10, 126.5, 127.5,
+                            -127.5, -128.5, 127.49, 128.0, -128.0, 254.5, 255.5, 1e6, -1e6, 3.0e38,
+                            float('inf'), float('-inf'), float('nan'), 0.499999, -0.499999, 1.5, 2.5,
+                            -1.5, -2.5, 0.25, -0.75])
+    rand = torch.randn(n_rand) * 3
+    return torch.cat([ties, special, rand]).to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# A. straight-through ops (seam 1)
+# ------------------------------------------------------------------------------------------------
+def gen_ste():
+    st = Store('ste_ops')
+    unary = ['round_ste', 'floor_ste', 'ceil_ste', 'round_to_zero_ste', 'dpu_round_ste',
+             'binary_sign_ste', 'ternary_sign_ste', 'abs_binary_sign_grad']
+    for dn, dtype in DT.items():
+        x = adversarial(dtype)
+        g = torch.randn(x.shape).to(dtype)
+        for name in unary:
+            xi = x.clone().requires_grad_(True)
+            y = getattr(ref_ste, name)(xi)
+            y.backward(g)
+            st.case({'op': name, 'dtype': dn}, x=x, g=g, y=y, dx=xi.grad)
+        for lo, hi in ((-1.5, 2.25), (1e-10, 6.0e4)):
+            xi = x.clone().requires_grad_(True)
+            y = ref_ste.scalar_clamp_ste(xi, lo, hi)
+            y.backward(g)
+            st.case({'op': 'scalar_clamp_ste', 'dtype': dn, 'lo': lo, 'hi': hi}, x=x, g=g, y=y, dx=xi.grad)
+        for lo in (1e-10, 0.3):
+            xi = x.clone().requires_grad_(True)
+            y = ref_ste.scalar_clamp_min_ste(xi, lo)
+            y.backward(g)
+            st.case({'op': 'scalar_clamp_min_ste', 'dtype': dn, 'lo': lo}, x=x, g=g, y=y, dx=xi.grad)
+        # tensor clamps: 0-dim bounds (the hot path: min_int/max_int) and same-shape bounds
+        lo0, hi0 = torch.tensor(-2.0).to(dtype), torch.tensor(1.75).to(dtype)
+        lof = (torch.rand(x.shape) - 1.5).to(dtype)
+        hif = (torch.rand(x.shape) + 0.5).to(dtype)
+        for tag, lo, hi in (('scalar', lo0, hi0), ('full', lof, hif)):
+            for name in ('tensor_clamp_ste', 'tensor_clamp'):
+                fn = getattr(ref_ste, name) if name.endswith('ste') else ref_ops.tensor_clamp
+                xi = x.clone().requires_grad_(True)
+                y = fn(xi, lo, hi)
+                y.backward(g)
+                st.case({'op': name, 'dtype': dn, 'bounds': tag}, x=x, g=g, lo=lo, hi=hi, y=y, dx=xi.grad)
+            # in-place variant: values only (B/function/ops.py:103-111: torch.min / torch.max)
+            xi = x.clone()
+            y = ref_ste.tensor_clamp_ste_(xi, lo, hi)
+            st.case({'op': 'tensor_clamp_ste_', 'dtype': dn, 'bounds': tag}, x=x, lo=lo, hi=hi, y=y)
+    # integer range formulas (B/function/ops.py:132-191)
+    for signed in (True, False):
+        for narrow in (True, False):
+            for bw in range(2, 9):
+                b = torch.tensor(float(bw))
+                st.case({'op': 'int_range', 'signed': signed, 'narrow': narrow, 'bit_width': bw},
+                        max_int=ref_ops.max_int(signed, narrow, b), min_int=ref_ops.min_int(signed, narrow, b))
+    st.save()
+
+
+# ------------------------------------------------------------------------------------------------
+# B. IntQuant forward / to_int / backward
+# ------------------------------------------------------------------------------------------------
+def gen_int_quant():
+    st = Store('int_quant')
+    shapes = {
+        'tensor': ((4, 1024), None),           # config 1 smoke shape, per-tensor
+        'ragged': ((3, 5, 7), None),           # 105 elements: not a multiple of any vector width
+        'ch0': ((6, 4, 3, 3), 0),              # weight-like, per output channel (dim 0), inner 36
+        'ch1': ((5, 6, 4, 4), 1),              # activation-like NCHW, per channel (dim 1), inner 16
+        'ch1_odd': ((3, 5, 7), 1),             # inner 7: scalar path
+        'chlast': ((9, 8), 1),                 # linear activation, per feature (inner 1)
+    }
+    cfgs = []
+    # (dtype of x, dtype of scale ('same'|'f32'|'bf16'), scale layout, signed, narrow, bw, zp kind, round, clamp)
+    for xd in ('f32', 'bf16', 'f16'):
+        for lay in ('tensor', 'ch0', 'ch1'):
+            cfgs.append((xd, 'same', lay, True, False, 8, 'zero', 'round', 'where'))
+            cfgs.append((xd, 'same', lay, True, True, 8, 'zero', 'round', 'ste'))
+    for xd in ('bf16', 'f16'):
+        cfgs.append((xd, 'f32', 'tensor', True, False, 8, 'zero', 'round', 'where'))   # 0-dim f32 scale: stays xd
+        cfgs.append((xd, 'f32', 'ch1', True, False, 8, 'zero', 'round', 'where'))      # f32 [1,C,1,1]: promotes to f32
+        cfgs.append((xd, 'f32', 'ch0', True, True, 4, 'zero', 'round', 'ste'))
+    for lay in ('ragged', 'ch1_odd', 'chlast'):
+        for xd in ('f32', 'bf16'):
+            cfgs.append((xd, 'same', lay, True, False, 8, 'zero', 'round', 'where'))
+    for bw in (2, 3, 4, 5, 6, 7):
+        cfgs.append(('f32', 'same', 'ch0', True, True, bw, 'zero', 'round', 'ste'))
+        cfgs.append(('bf16', 'same', 'tensor', False, False, bw, 'zero', 'round', 'where'))
+    cfgs.append(('f32', 'same', 'tensor', False, False, 8, 'zero', 'round', 'where'))
+    cfgs.append(('f32', 'same', 'tensor', False, True, 8, 'half', 'round', 'where'))
+    cfgs.append(('f32', 'same', 'ch1', False, False, 8, 'perch', 'round', 'where'))
+    cfgs.append(('bf16', 'same', 'ch1', False, False, 8, 'perch', 'round', 'where'))
+    cfgs.append(('bf16', 'f32', 'tensor', False, False, 8, 'half', 'round', 'where'))
+    for rm in ('floor', 'ceil', 'rtz', 'dpu'):
+        cfgs.append(('f32', 'same', 'tensor', True, False, 8, 'zero', rm, 'where'))
+        cfgs.append(('bf16', 'same', 'ch1', True, False, 6, 'half', rm, 'ste'))
+
+    for (xd, sd, lay, signed, narrow, bw, zpk, rm, clamp) in cfgs:
+        shape, chdim = shapes[lay]
+        dtype = DT[xd]
+        sdtype = dtype if sd == 'same' else DT[sd]
+        x = (torch.randn(shape) * 1.3)
+        # sprinkle adversarial values: exact ties, zeros, boundary hits
+        flat = x.view(-1)
+        adv = adversarial(torch.float32, n_rand=0)
+        adv = adv[torch.isfinite(adv)]
+        k = min(adv.numel(), flat.numel() // 3)
+        flat[torch.randperm(flat.numel())[:k]] = adv[:k] * 0.02
+        x = x.to(dtype)
+        if chdim is None:
+            scale = torch.tensor(0.02).to(sdtype)
+        else:
+            sshape = [1] * len(shape)
+            sshape[chdim] = shape[chdim]
+            scale = (torch.rand(sshape) * 0.03 + 0.005).to(sdtype)
+        qmax = float(ref_ops.max_int(signed, narrow, torch.tensor(float(bw))))
+        if zpk == 'zero':
+            zp = torch.tensor(0.0)
+        elif zpk == 'half':
+            zp = torch.tensor(float(int(qmax * 0.3)))
+        else:
+            zshape = [1] * len(shape)
+            zshape[chdim] = shape[chdim]
+            zp = torch.randint(0, int(qmax) // 2, zshape).float()
+        if zpk == 'perch':
+            zp = zp.to(sdtype)
+        bit_width = torch.tensor(float(bw))
+        iq = IntQuant(narrow_range=narrow, signed=signed, float_to_int_impl=ROUND_IMPL[rm](),
+                      tensor_clamp_impl=TensorClampSte() if clamp == 'ste' else TensorClamp())
+        xi = x.clone().requires_grad_(True)
+        si = scale.clone().requires_grad_(True)
+        zi = zp.clone().requires_grad_(True)
+        y = iq(si, zi, bit_width, xi)
+        g = torch.randn(y.shape).to(y.dtype)
+        y.backward(g)
+        with torch.no_grad():
+            yint = iq.to_int(scale, zp, bit_width, x)
+        st.case({'x_dtype': xd, 'layout': lay, 'shape': list(shape), 'chdim': chdim, 'signed': signed,
+                 'narrow': narrow, 'bit_width': bw, 'zp_kind': zpk, 'round': rm, 'clamp': clamp,
+                 'scalar_mode': 'opmath'},
+                x=x, scale=scale, zp=zp, g=g, y=y, y_int=yint, dx=xi.grad, dscale=si.grad, dzp=zi.grad)
+    st.save()
+
+
+# ------------------------------------------------------------------------------------------------
+# C. statistics
+# ------------------------------------------------------------------------------------------------
+def gen_stats():
+    st = Store('stats')
+    for dn, dtype in DT.items():
+        # whole tensor
+        for tag in ('rand', 'ties', 'zeros', 'nan'):
+            x = torch.randn(7, 33)
+            if tag == 'ties':
+                x = (x * 2).round() / 2
+                m = x.abs().max()
+                x[2, 5], x[4, 1], x[6, 30] = m, -m, m
+            if tag == 'zeros':
+                x = torch.zeros(3, 4)
+            if tag == 'nan':
+                x[3, 3] = float('nan')
+            x = x.to(dtype)
+            for name, mod in (('absmax', AbsMax()), ('absminmax', AbsMinMax())):
+                xi = x.clone().requires_grad_(True)
+                out = mod(OverTensorView()(xi))
+                gout = torch.tensor(0.7).to(out.dtype)
+                out.backward(gout)
+                st.case({'stat': name, 'dtype': dn, 'tag': tag, 'shape': list(x.shape), 'chdim': None},
+                        x=x, out=out, gout=gout, dx=xi.grad)
+        # per channel: weights (dim 0, no permute) and NCHW activations (dim 1, permute (1,0,2,3))
+        for lay, shape, chdim, perm in (('ch0', (6, 4, 3, 3), 0, None), ('ch1', (5, 6, 4, 4), 1, (1, 0, 2, 3)),
+                                        ('ch1_odd', (3, 5, 7), 1, (1, 0, 2))):
+            for tag in ('rand', 'ties'):
+                x = torch.randn(shape)
+                if tag == 'ties':
+                    x = (x * 2).round() / 2
+                if tag == 'ties' and lay == 'ch0':
+                    x[1] = 0.0
+                x = x.to(dtype)
+                for name, mod in (('absmax', AbsMax(1)), ('absminmax', AbsMinMax(1))):
+                    xi = x.clone().requires_grad_(True)
+                    out = mod(OverOutputChannelView(perm)(xi))
+                    gout = torch.randn(out.shape).to(out.dtype)
+                    out.backward(gout)
+                    st.case({'stat': name, 'dtype': dn, 'tag': tag, 'shape': list(shape), 'chdim': chdim},
+                            x=x, out=out, gout=gout, dx=xi.grad)
+    st.save()
+
+
+# ------------------------------------------------------------------------------------------------
+# D. resolved quantizer graphs
+# ------------------------------------------------------------------------------------------------
+def weight_quant(weight, bit_width, narrow=True):
+    """Int8WeightPerChannelFloat / its Int4 variant, resolved"""
+    cout = weight.shape[0]
+    scaling_shape = (cout,) + (1,) * (weight.dim() - 1)
+    return RescalingIntQuant(
+        IntQuant(narrow_range=narrow, signed=True, float_to_int_impl=RoundSte(),
+                 tensor_clamp_impl=TensorClampSte()),
+        StatsFromParameterScaling(AbsMax(1), OverOutputChannelView(None), 1, [weight],
+                                  FloatRestrictValue(), scaling_shape, affine_rescaling=False,
+                                  scaling_min_val=1e-10),
+        IntScaling(signed=True, narrow_range=narrow), ZeroZeroPoint(), BitWidthConst(bit_width))
+
+
+def act_quant_param_from_stats(collect_steps, per_channel_c=None):
+    """Int8ActPerTensorFloat with scaling_stats_op=MAX, resolved"""
+    if per_channel_c is None:
+        view, stats, shape = OverTensorView(), AbsMax(), ()
+    else:
+        view, stats, shape = OverOutputChannelView((1, 0, 2, 3)), AbsMax(1), (1, per_channel_c, 1, 1)
+    return RescalingIntQuant(
+        IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+        ParameterFromRuntimeStatsScaling(collect_steps, stats, view, shape, FloatRestrictValue(), 0.1, 1e-10),
+        IntScaling(signed=True, narrow_range=False), ZeroZeroPoint(), BitWidthConst(8))
+
+
+def act_quant_runtime_stats(per_channel_c=None):
+    if per_channel_c is None:
+        view, stats, shape = OverTensorView(), AbsMax(), ()
+    else:
+        view, stats, shape = OverOutputChannelView((1, 0, 2, 3)), AbsMax(1), (1, per_channel_c, 1, 1)
+    return RescalingIntQuant(
+        IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+        RuntimeStatsScaling(stats, view, FloatRestrictValue(), shape, affine_rescaling=False,
+                            scaling_stats_momentum=0.1, scaling_min_val=1e-10),
+        IntScaling(signed=True, narrow_range=False), ZeroZeroPoint(), BitWidthConst(8))
+
+
+def gen_graphs():
+    st = Store('quant_graphs')
+    # -- weights: config 2 (conv) and config 5 (linear, int4) at toy sizes ------------------------
+    for dn in ('f32', 'bf16'):
+        for tag, shape, bw in (('conv_int8', (16, 8, 3, 3), 8), ('linear_int4', (24, 40), 4),
+                               ('conv_int8_ragged', (5, 3, 3, 3), 8)):
+            w = torch.randn(shape) * 0.02
+            if tag == 'conv_int8':
+                w[3] = 0.0                      # all-zero channel exercises scaling_min_val
+                w[5].view(-1)[7] = w[5].abs().max()
+                w[5].view(-1)[2] = -w[5].abs().max()   # +-max tie: gradient goes to the first
+            w = torch.nn.Parameter(w.to(DT[dn]))
+            q = weight_quant(w, bw)
+            y, scale, zp, bwt = q(w)
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'graph': 'weight_per_channel', 'tag': tag, 'dtype': dn, 'bit_width': bw, 'shape': list(shape)},
+                    x=w.data, g=g, y=y, scale=scale, zp=zp, bit_width=bwt, dx=w.grad)
+    # -- activations, runtime stats (training EMA then eval) --------------------------------------
+    for dn in ('f32', 'bf16'):
+        for tag, pc in (('per_tensor', None), ('per_channel', 6)):
+            q = act_quant_runtime_stats(pc)
+            q.train()
+            for step in range(3):
+                x = (torch.randn(4, 6, 5, 5) * (1.0 + step)).to(DT[dn])
+                xi = x.clone().requires_grad_(True)
+                y, scale, zp, bwt = q(xi)
+                g = torch.randn(y.shape).to(y.dtype)
+                y.backward(g)
+                st.case({'graph': 'act_runtime_stats', 'tag': tag, 'dtype': dn, 'step': step, 'training': True,
+                         'channels': pc},
+                        x=x, g=g, y=y, scale=scale, dx=xi.grad,
+                        running_stats=q.scaling_impl.runtime_stats.running_stats.clone())
+            q.eval()
+            xi = x.clone().requires_grad_(True)
+            y, scale, zp, bwt = q(xi)
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'graph': 'act_runtime_stats', 'tag': tag, 'dtype': dn, 'step': 3, 'training': False,
+                     'channels': pc},
+                    x=x, g=g, y=y, scale=scale, dx=xi.grad,
+                    running_stats=q.scaling_impl.runtime_stats.running_stats.clone())
+    # -- activations, stats collection then learned parameter (Int8ActPerTensorFloat, MAX stats) ---
+    for dn in ('f32', 'bf16'):
+        for tag, pc in (('per_tensor', None), ('per_channel', 6)):
+            q = act_quant_param_from_stats(2, pc)
+            q.train()
+            for step in range(4):
+                x = (torch.randn(4, 6, 5, 5) * (1.0 + 0.5 * step)).to(DT[dn])
+                xi = x.clone().requires_grad_(True)
+                q.zero_grad()
+                y, scale, zp, bwt = q(xi)
+                g = torch.randn(y.shape).to(y.dtype)
+                y.backward(g)
+                si = q.scaling_impl
+                st.case({'graph': 'act_param_from_stats', 'tag': tag, 'dtype': dn, 'step': step, 'channels': pc,
+                         'counter': int(si.counter)},
+                        x=x, g=g, y=y, scale=scale, dx=xi.grad, buffer=si.buffer.clone(),
+                        value=si.value.detach().clone(),
+                        dvalue=si.value.grad.clone() if si.value.grad is not None else None)
+            sd = {k: v for k, v in q.state_dict().items()}
+            st.case({'graph': 'act_param_from_stats_state_dict', 'tag': tag, 'dtype': dn, 'keys': sorted(sd.keys())},
+                    **{k.replace('.', '__'): v for k, v in sd.items()})
+    # -- learned per-tensor scale, steady state (ParameterScaling) ---------------------------------
+    for dn in ('f32', 'bf16'):
+        for cast_module in (False, True):
+            q = RescalingIntQuant(
+                IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+                ParameterScaling(3.0, scaling_shape=None, restrict_scaling_impl=FloatRestrictValue(),
+                                 scaling_min_val=1e-10),
+                IntScaling(signed=True, narrow_range=False), ZeroZeroPoint(), BitWidthConst(8))
+            if cast_module:
+                if dn == 'f32':
+                    continue
+                q = q.to(DT[dn])
+            x = (torch.randn(4, 6, 5, 5) * 1.2).to(DT[dn])
+            xi = x.clone().requires_grad_(True)
+            y, scale, zp, bwt = q(xi)
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'graph': 'act_parameter_scale', 'dtype': dn, 'module_cast': cast_module},
+                    x=x, g=g, y=y, scale=scale, dx=xi.grad, dvalue=q.scaling_impl.value.grad,
+                    value=q.scaling_impl.value.detach())
+    # -- const scale (reference doctest graph, B/core/quant/int.py:113-134) -------------------------
+    q = RescalingIntQuant(IntQuant(narrow_range=True, signed=True), ConstScaling(0.1),
+                          IntScaling(signed=True, narrow_range=True), ZeroZeroPoint(), BitWidthConst(4))
+    x = torch.Tensor([0.042, -0.053, 0.31, -0.44])
+    y, scale, zp, bwt = q(x)
+    st.case({'graph': 'const_scale_doctest'}, x=x, y=y, scale=scale, zp=zp, bit_width=bwt)
+    st.save()
+
+
+if __name__ == '__main__':
+    torch.manual_seed(123456)
+    torch.set_num_threads(1)
+    gen_ste()
+    gen_int_quant()
+    gen_stats()
+    gen_graphs()
