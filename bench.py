@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""Headline benchmark: fused int8 fake-quant fwd+bwd, per-channel, [256,512,56,56] bf16 (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in
+HBM: the forward of a stats-scaled per-channel activation quantizer (AbsMax statistic over (N,H,W),
+scale = max(stat, 1e-10)/128, quantize-dequantize; RescalingIntQuant with RuntimeStatsScaling in
+training mode) followed by its full autograd backward (clamp mask, scale-gradient
+reduction, deposit on the arg-max elements).  Nothing is skipped or cached between steps.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the batch is sharded, every rank holds
+its own [256,512,56,56] shard (weak scaling), and the only exchange is the all-reduce of the
+per-channel statistic (RCCL, <= 4 KB) in forward and of the scale gradient in backward
+(brevitas_amd.distributed).  value = elements quantized by all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (the backward) priced in algorithmic HBM bytes per launch over its
+                  HIP-event duration measured inside the timed region, against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (a port of the reference algorithm, oracle/) timed on this host's cores
+                  on a bounded sample of the same workload.  Baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (shape, dtype, per_channel, description)
+    'act_per_channel_bf16': ((256, 512, 56, 56), torch.bfloat16, True,
+                             'Int8 per-channel act fake-quant fwd+bwd, AbsMax stats, [256,512,56,56] bf16'),
+    'act_per_tensor_bf16': ((256, 512, 56, 56), torch.bfloat16, False,
+                            'Int8ActPerTensorFloat(MAX stats) fwd+bwd, [256,512,56,56] bf16'),
+    'act_per_channel_f32': ((256, 512, 56, 56), torch.float32, True,
+                            'Int8 per-channel act fake-quant fwd+bwd, AbsMax stats, [256,512,56,56] f32'),
+}
+
+
+def build_quantizer(channels, per_channel, device, group=None):
+    from brevitas_amd.core.bit_width import BitWidthConst
+    from brevitas_amd.core.function_wrapper import OverOutputChannelView, OverTensorView, RoundSte, TensorClamp
+    from brevitas_amd.core.quant import IntQuant, RescalingIntQuant
+    from brevitas_amd.core.restrict_val import FloatRestrictValue
+    from brevitas_amd.core.scaling import IntScaling, RuntimeStatsScaling
+    from brevitas_amd.core.stats import AbsMax
+    from brevitas_amd.core.zero_point import ZeroZeroPoint
+    if per_channel:
+        view, stats, shape = OverOutputChannelView((1, 0, 2, 3)), AbsMax(1), (1, channels, 1, 1)
+    else:
+        view, stats, shape = OverTensorView(), AbsMax(), ()
+    q = RescalingIntQuant(
+        IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+        RuntimeStatsScaling(stats, view, FloatRestrictValue(), shape, affine_rescaling=False,
+                            scaling_stats_momentum=0.1, scaling_min_val=1e-10),
+        IntScaling(signed=True, narrow_range=False), ZeroZeroPoint(), BitWidthConst(8)).to(device)
+    q.train()
+    if group is not None:
+        from brevitas_amd.distributed import shard_over_batch
+        shard_over_batch(q, group)
+    return q
+
+
+class KernelTimer:
+    """HIP-event brackets around one named C-ABI call, on the stream it is launched on"""
+
+    def __init__(self, name):
+        self.name = name
+        self.pairs = []
+        self.enabled = False
+
+    def before(self, name):
+        if self.enabled and name == self.name:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.pairs.append([ev, None])
+
+    def after(self, name):
+        if self.enabled and name == self.name and self.pairs and self.pairs[-1][1] is None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.pairs[-1][1] = ev
+
+    def mean_ms(self):
+        ts = [a.elapsed_time(b) for a, b in self.pairs if b is not None]
+        return sum(ts) / len(ts) if ts else None
+
+
+def cpu_baseline(shape, dtype, per_channel, budget_s=12.0):
+    """time the oracle (oracle/, a port of the reference algorithm) on a bounded sample"""
+    import numpy as np
+
+    import oracle as O
+    O.build()
+    n_full, c, h, w = shape
+    n = 8  # 1/32 of the batch: Gelem/s is size independent to first order
+    code = {torch.float32: O.F32, torch.bfloat16: O.BF16, torch.float16: O.F16}[dtype]
+    g = torch.Generator().manual_seed(123456)
+    x = torch.randn(n, c, h, w, generator=g).to(dtype)
+    gr = torch.randn(n, c, h, w, generator=g).to(dtype)
+    xn, _ = O.from_torch(x.reshape(-1))
+    gn, _ = O.from_torch(gr.reshape(-1))
+    if per_channel:
+        d = O.make_desc(n, c, h * w, code, code, code, O.F32, scale_per_channel=True, qmin=-128.0, qmax=127.0)
+    else:
+        d = O.make_desc(1, 1, n * c * h * w, code, code, code, O.F32, scale_per_channel=False, qmin=-128.0,
+                        qmax=127.0)
+    O.step_stats_scaled(d, xn, gn, 1e-10, 128.0)  # warm-up
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        O.step_stats_scaled(d, xn, gn, 1e-10, 128.0)
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= 50:
+            break
+    elems = n * c * h * w
+    return {
+        'value': round(elems * iters / el / 1e9, 4), 'unit': 'Gelem/s', 'cores': O.num_threads(), 'kind': 'port',
+        'sample': '[%d,%d,%d,%d] %s (1/%d of the batch), %d iterations in %.1f s of the C oracle '
+                  '(oracle/bvq_oracle.c, OpenMP)' % (n, c, h, w, str(dtype).replace('torch.', ''), n_full // n,
+                                                      iters, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='act_per_channel_bf16', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm device (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+        group = dist.group.WORLD
+
+    from brevitas_amd import _native as nat
+    shape, dtype, per_channel, descr = WORKLOADS[args.workload]
+    torch.manual_seed(123456 + rank)
+    x = torch.randn(shape, device=device, dtype=dtype).requires_grad_(True)
+    g = torch.randn(shape, device=device, dtype=dtype)
+    q = build_quantizer(shape[1], per_channel, device, group)
+    n_elem = x.numel()
+
+    timer = KernelTimer('bvq_fakequant_bwd')
+    nat.set_kernel_timer(timer)
+
+    def step():
+        x.grad = None
+        y, scale, zp, bw = q(x)
+        y.backward(g)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_elem * world * args.steps / elapsed / 1e9
+        b = x.element_size()
+        # algorithmic bytes of the backward kernel per launch: read g + read x + write dx
+        bwd_bytes = 3 * b * n_elem
+        bwd_ms = timer.mean_ms()
+        achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get(args.workload, {}).get('bvq_fakequant_bwd')
+        out = {
+            'metric': 'Gelem/s fused int8 fake-quant fwd+bwd, per-channel, [256,512,56,56]',
+            'value': round(value, 3), 'unit': 'Gelem/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': str(dtype).replace('torch.', '').replace(
+                'bfloat16', 'bf16').replace('float32', 'f32'),
+            'data': 'synthetic',
+            'config': {'workload': descr, 'name': args.workload, 'shape_per_gpu': list(shape),
+                       'quantizer': 'RescalingIntQuant(IntQuant(int8, TensorClamp), RuntimeStatsScaling(AbsMax), '
+                                    'IntScaling, ZeroZeroPoint, BitWidthConst(8)), training mode',
+                       'parallelism': 'batch-sharded x%d, all-reduce(MAX) of the statistic' % world
+                       if world > 1 else 'single GPU',
+                       'algorithmic_bytes_per_elem': 6 * b},
+            'hbm_frac_whole_step': round(6 * b * n_elem / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            'roofline': {'kernel': 'fakequant_bwd_kernel (bvq_fakequant_bwd)', 'bound': 'hbm',
+                         'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                         'traffic': traffic, 'algorithmic_bytes_per_launch': bwd_bytes,
+                         'avg_launch_ms': round(bwd_ms, 4) if bwd_ms else None},
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(shape, dtype, per_channel)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

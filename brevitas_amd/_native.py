@@ -1,0 +1,278 @@
+"""ctypes binding of libbvq.so -- the C-ABI HIP library (include/bvq.h).
+
+This is the ONLY compute backend of the package: there is no CPU or pure-torch fallback.  If the
+library is missing, or a tensor does not live on a ROCm device, the call fails loudly.
+
+PyTorch is used here as plumbing only: device memory (torch.empty), the current HIP stream and the
+device guard.  Signatures carry raw pointers and sizes.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libbvq.so')
+
+F32, BF16, F16 = 0, 1, 2
+ROUND, FLOOR, CEIL, ROUND_TO_ZERO, DPU_ROUND = range(5)
+(OP_ROUND, OP_FLOOR, OP_CEIL, OP_ROUND_TO_ZERO, OP_DPU_ROUND, OP_BINARY_SIGN, OP_TERNARY_SIGN,
+ OP_ABS) = range(8)
+STAT_ABSMAX, STAT_MINMAX = 0, 1
+SCALAR_OPMATH, SCALAR_CAST = 0, 1
+OUT_DEQUANT, OUT_INT = 0, 1
+MATCH_ABS, MATCH_VALUE = 0, 1
+ABI_VERSION = 1
+
+_DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+EXPORTS = (
+    'bvq_abi_version', 'bvq_last_error', 'bvq_unary', 'bvq_scalar_clamp', 'bvq_tensor_clamp',
+    'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
+    'bvq_stat_bwd', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
+
+
+class QuantDesc(ctypes.Structure):
+    """bvq_quant_desc of include/bvq.h"""
+    _fields_ = [
+        ('outer', ctypes.c_int64), ('channels', ctypes.c_int64), ('inner', ctypes.c_int64),
+        ('x_dtype', ctypes.c_int32), ('ct_dtype', ctypes.c_int32), ('scale_dtype', ctypes.c_int32),
+        ('zp_dtype', ctypes.c_int32), ('scale_per_channel', ctypes.c_int32),
+        ('zp_per_channel', ctypes.c_int32), ('qmin', ctypes.c_float), ('qmax', ctypes.c_float),
+        ('round_mode', ctypes.c_int32), ('scalar_mode', ctypes.c_int32), ('clamp_ste', ctypes.c_int32),
+        ('out_kind', ctypes.c_int32)]
+
+
+class BvqError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'brevitas_amd: %s is missing. Build it with `python -m brevitas_amd.csrc.build` '
+            '(needs hipcc, gfx950). There is no fallback backend.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
+    lib.bvq_abi_version.restype = i32
+    lib.bvq_last_error.restype = ctypes.c_char_p
+    sig = {
+        'bvq_unary': (i32, [i32, i32, vp, vp, i64, vp]),
+        'bvq_scalar_clamp': (i32, [i32, vp, vp, i64, dbl, i32, dbl, i32, vp]),
+        'bvq_tensor_clamp': (i32, [i32, vp, vp, vp, i32, vp, i64, vp]),
+        'bvq_tensor_clamp_bwd': (i32, [i32, vp, vp, vp, vp, i32, vp, i64, vp]),
+        'bvq_abs_binary_sign_grad_bwd': (i32, [i32, vp, vp, vp, i64, vp]),
+        'bvq_stats_workspace_bytes': (i64, [i32, i32, i64, i64, i64]),
+        'bvq_stats': (i32, [i32, i32, vp, i64, i64, i64, i32, vp, vp, i64, vp]),
+        'bvq_stat_bwd': (i32, [i32, i32, vp, vp, vp, vp, i64, i64, i64, i32, vp, i64, vp]),
+        'bvq_fakequant_fwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp]),
+        'bvq_fakequant_bwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
+        'bvq_fakequant_bwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.bvq_abi_version()
+    if ver != ABI_VERSION:
+        raise ImportError('brevitas_amd: libbvq.so has ABI %d, this package needs %d' % (ver, ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    return lib.bvq_last_error().decode()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise BvqError('%s failed (%d): %s' % (what, rc, last_error()))
+
+
+def dtype_code(dtype):
+    try:
+        return _DTYPES[dtype]
+    except KeyError:
+        raise BvqError('brevitas_amd: unsupported dtype %s (float32, bfloat16, float16)' % dtype)
+
+
+def require_device(*tensors):
+    """every tensor must live on the same ROCm device; no CPU path exists"""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise BvqError(
+                'brevitas_amd: got a %s tensor; the fake-quantization engine only runs on a ROCm '
+                'device (there is no CPU fallback)' % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise BvqError('brevitas_amd: tensors on different devices (%s, %s)' % (dev, t.device))
+    return dev
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# Optional measurement hook (bench.py): an object with before(name) / after(name), called around the
+# C-ABI calls listed below on the launching thread, e.g. to record HIP events on the current stream.
+_timer = None
+
+
+def set_kernel_timer(timer):
+    global _timer
+    _timer = timer
+
+
+# ---- thin wrappers: allocate outputs with torch, pass raw pointers --------------------------------
+
+def unary(op, x):
+    dev = require_device(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        check(lib.bvq_unary(op, dtype_code(x.dtype), ptr(x), ptr(y), x.numel(), stream_ptr(dev)), 'bvq_unary')
+    return y
+
+
+def scalar_clamp(x, lo, hi):
+    dev = require_device(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        check(lib.bvq_scalar_clamp(dtype_code(x.dtype), ptr(x), ptr(y), x.numel(),
+                                   0.0 if lo is None else float(lo), int(lo is not None),
+                                   0.0 if hi is None else float(hi), int(hi is not None), stream_ptr(dev)),
+              'bvq_scalar_clamp')
+    return y
+
+
+def _bounds(x, lo, hi):
+    """bring clamp bounds to x's dtype/device; returns (lo, hi, bounds_full)"""
+    lo = lo.to(device=x.device, dtype=x.dtype)
+    hi = hi.to(device=x.device, dtype=x.dtype)
+    if lo.numel() == 1 and hi.numel() == 1:
+        return lo.reshape(1), hi.reshape(1), 0
+    return lo.expand_as(x).contiguous(), hi.expand_as(x).contiguous(), 1
+
+
+def tensor_clamp(x, lo, hi, out=None):
+    dev = require_device(x)
+    xc = x.contiguous()
+    lo, hi, full = _bounds(xc, lo, hi)
+    y = out if out is not None else torch.empty_like(xc)
+    with torch.cuda.device(dev):
+        check(lib.bvq_tensor_clamp(dtype_code(xc.dtype), ptr(xc), ptr(lo), ptr(hi), full, ptr(y), xc.numel(),
+                                   stream_ptr(dev)), 'bvq_tensor_clamp')
+    return y
+
+
+def tensor_clamp_bwd(g, x, lo, hi):
+    dev = require_device(g, x)
+    xc = x.contiguous()
+    g = g.to(xc.dtype).contiguous()
+    lo, hi, full = _bounds(xc, lo, hi)
+    dx = torch.empty_like(xc)
+    with torch.cuda.device(dev):
+        check(lib.bvq_tensor_clamp_bwd(dtype_code(xc.dtype), ptr(g), ptr(xc), ptr(lo), ptr(hi), full, ptr(dx),
+                                       xc.numel(), stream_ptr(dev)), 'bvq_tensor_clamp_bwd')
+    return dx
+
+
+def abs_binary_sign_grad_bwd(g, x):
+    dev = require_device(g, x)
+    xc = x.contiguous()
+    g = g.to(xc.dtype).contiguous()
+    dx = torch.empty_like(xc)
+    with torch.cuda.device(dev):
+        check(lib.bvq_abs_binary_sign_grad_bwd(dtype_code(xc.dtype), ptr(g), ptr(xc), ptr(dx), xc.numel(),
+                                               stream_ptr(dev)), 'bvq_abs_binary_sign_grad_bwd')
+    return dx
+
+
+def stats(kind, x, outer, channels, inner, out_f32=False):
+    """x contiguous, viewed as [outer, channels, inner] -> [channels] (ABSMAX) or [2, channels]"""
+    dev = require_device(x)
+    assert x.is_contiguous() and x.numel() == outer * channels * inner
+    dt = dtype_code(x.dtype)
+    nout = channels * (2 if kind == STAT_MINMAX else 1)
+    out = torch.empty(nout, dtype=torch.float32 if out_f32 else x.dtype, device=dev)
+    wsb = lib.bvq_stats_workspace_bytes(kind, dt, outer, channels, inner)
+    if wsb < 0:
+        raise BvqError('bvq_stats_workspace_bytes: bad arguments')
+    ws = torch.empty(max(int(wsb), 8), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        if _timer is not None:
+            _timer.before('bvq_stats')
+        check(lib.bvq_stats(kind, dt, ptr(x), outer, channels, inner, dtype_code(out.dtype), ptr(out), ptr(ws),
+                            ws.numel(), stream_ptr(dev)), 'bvq_stats')
+        if _timer is not None:
+            _timer.after('bvq_stats')
+    return out
+
+
+def stat_bwd(match, x, stat, gstat, outer, channels, inner, dx=None):
+    """dense (dx None) or in-place additive (dx given) backward of a max/min statistic"""
+    dev = require_device(x, stat, gstat, dx)
+    assert x.is_contiguous()
+    dt = dtype_code(x.dtype)
+    stat = stat.to(x.dtype).contiguous()
+    gstat = gstat.to(x.dtype).contiguous()
+    mode_add = int(dx is not None)
+    if dx is None:
+        dx = torch.empty_like(x)
+    assert dx.is_contiguous() and dx.dtype == x.dtype
+    wsb = lib.bvq_stats_workspace_bytes(STAT_ABSMAX, dt, outer, channels, inner)
+    ws = torch.empty(max(int(wsb), 8), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.bvq_stat_bwd(match, dt, ptr(x), ptr(stat), ptr(gstat), ptr(dx), outer, channels, inner,
+                               mode_add, ptr(ws), ws.numel(), stream_ptr(dev)), 'bvq_stat_bwd')
+    return dx
+
+
+def fakequant_fwd(desc, x, scale, zp, want_codes=False):
+    dev = require_device(x, scale, zp)
+    ct = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[desc.ct_dtype]
+    y = torch.empty(x.shape, dtype=ct, device=dev)
+    codes = torch.empty(x.shape, dtype=torch.int32, device=dev) if want_codes else None
+    with torch.cuda.device(dev):
+        if _timer is not None:
+            _timer.before('bvq_fakequant_fwd')
+        check(lib.bvq_fakequant_fwd(ctypes.byref(desc), ptr(x), ptr(scale), ptr(zp), ptr(y), ptr(codes),
+                                    stream_ptr(dev)), 'bvq_fakequant_fwd')
+        if _timer is not None:
+            _timer.after('bvq_fakequant_fwd')
+    return (y, codes) if want_codes else y
+
+
+def fakequant_bwd(desc, g, x, scale, zp, need_dscale, need_dzp):
+    dev = require_device(g, x, scale, zp)
+    dx = torch.empty_like(x)
+    pc = (desc.scale_per_channel or desc.zp_per_channel) and desc.channels > 1
+    nsum = int(desc.channels) if pc else 1
+    ds = torch.empty(nsum, dtype=torch.float32, device=dev) if need_dscale else None
+    dz = torch.empty(nsum, dtype=torch.float32, device=dev) if need_dzp else None
+    ws = None
+    wsb = 0
+    if need_dscale or need_dzp:
+        wsb = int(lib.bvq_fakequant_bwd_workspace_bytes(ctypes.byref(desc)))
+        if wsb < 0:
+            raise BvqError('bvq_fakequant_bwd_workspace_bytes: ' + last_error())
+        ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        if _timer is not None:
+            _timer.before('bvq_fakequant_bwd')
+        check(lib.bvq_fakequant_bwd(ctypes.byref(desc), ptr(g), ptr(x), ptr(scale), ptr(zp), ptr(dx), ptr(ds),
+                                    ptr(dz), ptr(ws), wsb, stream_ptr(dev)), 'bvq_fakequant_bwd')
+        if _timer is not None:
+            _timer.after('bvq_fakequant_bwd')
+    return dx, ds, dz

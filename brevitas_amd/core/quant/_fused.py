@@ -1,0 +1,178 @@
+"""Autograd entry points of the fused quantizer kernels.
+
+FakeQuantFn        x, scale, zero_point  ->  y                  (IntQuant.forward in one kernel)
+StatsFakeQuantFn   x                     ->  y, scale, stat     (AbsMax -> scale -> IntQuant in
+                                                                 three kernels, backward with the
+                                                                 arg-max deposit folded into dx)
+
+Both reproduce the reference's type promotion: the compute dtype is torch.result_type(x, scale),
+every intermediate is rounded to it, the output has it, and the gradient w.r.t. x comes back in
+x's dtype.  Layouts the kernels do not cover make `plan()` return None and the caller falls back
+to the op-by-op composition (same results, more passes).
+"""
+from typing import NamedTuple, Optional
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+import brevitas_amd.config as config
+from brevitas_amd import _native as nat
+
+_FLOATS = (torch.float32, torch.bfloat16, torch.float16)
+
+
+class Plan(NamedTuple):
+    outer: int
+    channels: int
+    inner: int
+    scale_pc: bool
+    zp_pc: bool
+    ct: torch.dtype
+
+
+def _channel_dim(x: Tensor, t: Tensor):
+    """None: one element (per-tensor); int: the single broadcast dim; -1: not a per-channel layout"""
+    if t.numel() == 1:
+        return None
+    if t.dim() > x.dim():
+        return -1
+    shape = (1,) * (x.dim() - t.dim()) + tuple(t.shape)
+    nz = [i for i, s in enumerate(shape) if s != 1]
+    if len(nz) != 1 or shape[nz[0]] != x.shape[nz[0]]:
+        return -1
+    return nz[0]
+
+
+def plan(x: Tensor, scale: Tensor, zp: Tensor) -> Optional[Plan]:
+    """how (and whether) the fused kernels can run IntQuant on these operands"""
+    if not (x.is_cuda and scale.is_cuda and zp.is_cuda) or x.dim() == 0 or x.numel() == 0:
+        return None
+    if x.dtype not in _FLOATS or scale.dtype not in _FLOATS or zp.dtype not in _FLOATS:
+        return None
+    if scale.dim() > x.dim() or zp.dim() > x.dim():
+        return None
+    sd, zd = _channel_dim(x, scale), _channel_dim(x, zp)
+    if sd == -1 or zd == -1 or (sd is not None and zd is not None and sd != zd):
+        return None
+    ct = torch.result_type(x, scale)
+    # a 0-dim zero-point never promotes a dimensioned tensor; a dimensioned one must not either
+    if zp.dim() > 0 and torch.promote_types(ct, zp.dtype) != ct:
+        return None
+    if not (ct == x.dtype or ct == torch.float32):
+        return None
+    cd = sd if sd is not None else zd
+    if cd is None:
+        return Plan(1, 1, x.numel(), False, False, ct)
+    outer = 1
+    for s in x.shape[:cd]:
+        outer *= s
+    inner = 1
+    for s in x.shape[cd + 1:]:
+        inner *= s
+    return Plan(outer, x.shape[cd], inner, sd is not None, zd is not None, ct)
+
+
+def scalar_mode():
+    return nat.SCALAR_CAST if config.SCALAR_OPERAND_MODE == 'device' else nat.SCALAR_OPMATH
+
+
+def make_desc(p: Plan, x: Tensor, scale: Tensor, zp: Tensor, qmin, qmax, round_mode, clamp_ste, out_kind):
+    return nat.QuantDesc(p.outer, p.channels, p.inner, nat.dtype_code(x.dtype), nat.dtype_code(p.ct),
+                         nat.dtype_code(scale.dtype), nat.dtype_code(zp.dtype), int(p.scale_pc), int(p.zp_pc),
+                         qmin, qmax, round_mode, scalar_mode(), int(clamp_ste), out_kind)
+
+
+def _reduce_like(sums: Tensor, like: Tensor) -> Tensor:
+    """per-channel float32 sums -> gradient shaped and typed like `like`"""
+    if like.numel() == 1 and sums.numel() > 1:
+        sums = sums.sum()
+    return sums.reshape(like.shape).to(like.dtype)
+
+
+class FakeQuantFn(Function):
+    """IntQuant.forward / IntQuant.to_int on the fused kernel (B/core/quant/int_base.py:63-97)"""
+
+    @staticmethod
+    def forward(ctx, x, scale, zp, p, qmin, qmax, round_mode, clamp_ste, out_kind):
+        xc = x.contiguous()
+        sc = scale.reshape(-1).contiguous()
+        zc = zp.reshape(-1).contiguous()
+        desc = make_desc(p, xc, sc, zc, qmin, qmax, round_mode, clamp_ste, out_kind)
+        y = nat.fakequant_fwd(desc, xc, sc, zc)
+        ctx.desc = desc
+        ctx.save_for_backward(xc, scale, zp)
+        if out_kind == nat.OUT_INT:
+            ctx.mark_non_differentiable(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, scale, zp = ctx.saved_tensors
+        desc = ctx.desc
+        need_ds, need_dz = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
+        gy = gy.to(ct).contiguous()
+        dx, ds, dz = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1).contiguous(),
+                                       need_ds, need_dz)
+        ds = _reduce_like(ds, scale) if need_ds else None
+        dz = _reduce_like(dz, zp) if need_dz else None
+        return dx, ds, dz, None, None, None, None, None, None
+
+
+class StatsPlan(NamedTuple):
+    outer: int
+    channels: int
+    inner: int
+    scaling_shape: tuple
+    min_val: float
+
+
+class StatsFakeQuantFn(Function):
+    """AbsMax statistic -> clamp_min(min_val) -> / int_threshold -> IntQuant, zero zero-point.
+
+    The resolved graphs of Int8WeightPerChannelFloat (StatsFromParameterScaling) and of stats-scaled
+    activations (RuntimeStatsScaling in training): SURVEY 8a.  Forward: read x (reduce), read x, write
+    y.  Backward: read g, read x, write dx; the statistic's gradient is deposited on the arg-max
+    element(s) of dx in place instead of materialising the dense gradient torch.max would return.
+    """
+
+    @staticmethod
+    def forward(ctx, x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste):
+        xc = x.contiguous()
+        flat = xc.reshape(-1)
+        stat = nat.stats(nat.STAT_ABSMAX, flat, sp.outer, sp.channels, sp.inner)
+        # _StatsScaling with float restriction: scalar_clamp_min_ste (B/core/restrict_val.py:22-42)
+        thr = nat.scalar_clamp(stat, sp.min_val, None) if sp.min_val else stat
+        # RescalingIntQuant.forward: scale = threshold / int_threshold (B/core/quant/int.py:160),
+        # on tensors shaped like the reference's so that type promotion is the same
+        scale = thr.view(sp.scaling_shape) / int_threshold
+        zp = torch.zeros((), dtype=torch.float32, device=x.device)
+        p = plan(xc, scale, zp)
+        if p is None:
+            raise nat.BvqError('StatsFakeQuantFn: unsupported operand layout (caller must pre-check)')
+        sc = scale.reshape(-1).contiguous()
+        desc = make_desc(p, xc, sc, zp.reshape(-1), qmin, qmax, round_mode, clamp_ste, nat.OUT_DEQUANT)
+        y = nat.fakequant_fwd(desc, xc, sc, zp.reshape(-1))
+        ctx.desc = desc
+        ctx.sp = sp
+        ctx.save_for_backward(xc, scale, zp, stat, int_threshold)
+        stat_out = stat.view(sp.scaling_shape)
+        ctx.mark_non_differentiable(stat_out)
+        return y, scale, stat_out
+
+    @staticmethod
+    def backward(ctx, gy, gscale, _gstat):
+        xc, scale, zp, stat, int_threshold = ctx.saved_tensors
+        desc, sp = ctx.desc, ctx.sp
+        ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
+        gy = gy.to(ct).contiguous()
+        dx, ds, _ = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), True, False)
+        ds = _reduce_like(ds, scale)
+        if gscale is not None:
+            ds = ds + gscale
+        # scale = thr / int_threshold  ->  dthr = dscale / int_threshold ; clamp_min_ste passes it on
+        dstat = (ds / int_threshold).to(stat.dtype).reshape(-1).contiguous()
+        nat.stat_bwd(nat.MATCH_ABS, xc.reshape(-1), stat, dstat, sp.outer, sp.channels, sp.inner,
+                     dx=dx.reshape(-1))
+        return dx, None, None, None, None, None, None

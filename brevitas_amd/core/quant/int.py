@@ -1,0 +1,133 @@
+"""RescalingIntQuant (drop-in for B/core/quant/int.py:94-163): obtains bit width, scale and zero
+point from its sub-modules and applies IntQuant; returns (y, scale, zero_point, bit_width).
+
+Sub-module attribute names (`int_quant`, `scaling_impl`, `int_scaling_impl`, `zero_point_impl`,
+`msb_clamp_bit_width_impl`) are the reference's: they are part of state-dict keys and are
+introspected by proxies.
+
+Two recognised graphs skip the op-by-op orchestration and run as statistic kernel + tiny scale
+ops + quantize kernel, with a backward that never materialises torch.max's dense gradient:
+  * weights:      StatsFromParameterScaling(AbsMax) tracking exactly the tensor being quantized
+                  (Int8WeightPerChannelFloat and friends);
+  * activations:  RuntimeStatsScaling(AbsMax) in training mode.
+Everything else takes the generic route below, which is the reference's own sequence.
+"""
+from typing import Tuple
+
+import torch
+from torch import Tensor
+from torch.nn import Module
+
+import brevitas_amd.config as config
+from brevitas_amd.core.function_wrapper.shape import OverOutputChannelView, OverTensorView
+from brevitas_amd.core.quant import _fused
+from brevitas_amd.core.quant.delay import _NoDelay
+from brevitas_amd.core.quant.int_base import IntQuant
+from brevitas_amd.core.scaling.int_scaling import IntScaling
+from brevitas_amd.core.scaling.runtime import RuntimeStatsScaling, StatsFromParameterScaling
+from brevitas_amd.core.stats.stats_op import AbsMax
+from brevitas_amd.core.zero_point import ZeroZeroPoint
+from brevitas_amd.function.ops import int_range_host
+
+
+class RescalingIntQuant(torch.nn.Module):
+    """
+    Examples (B/core/quant/int.py:113-134):
+        >>> q = RescalingIntQuant(IntQuant(narrow_range=True, signed=True), ConstScaling(0.1),
+        ...                       IntScaling(signed=True, narrow_range=True), ZeroZeroPoint(), BitWidthConst(4))
+        >>> out, scale, zero_point, bit_width = q(torch.Tensor([0.042, -0.053, 0.31, -0.44]))
+        >>> out
+        tensor([ 0.0429, -0.0571,  0.1000, -0.1000])
+    """
+
+    def __init__(self, int_quant: Module, scaling_impl: Module, int_scaling_impl: Module, zero_point_impl: Module,
+                 bit_width_impl: Module):
+        super().__init__()
+        self.int_quant = int_quant
+        self.scaling_impl = scaling_impl
+        self.int_scaling_impl = int_scaling_impl
+        self.zero_point_impl = zero_point_impl
+        self.msb_clamp_bit_width_impl = bit_width_impl
+
+    # ---- recognised graphs -----------------------------------------------------------------------------
+
+    def _stats_plan(self, x: Tensor, bit_width: Tensor):
+        """StatsPlan + the module owning a running average (or None), if a fused graph applies"""
+        if not config.FUSED_PATHS or not x.is_cuda or x.dim() == 0 or x.numel() == 0:
+            return None
+        iq = self.int_quant
+        if type(iq) is not IntQuant or not isinstance(iq.delay_wrapper.delay_impl, _NoDelay):
+            return None
+        if getattr(iq.float_to_int_impl, 'bvq_round_mode', None) is None or \
+                getattr(iq.tensor_clamp_impl, 'bvq_clamp_ste', None) is None:
+            return None
+        if type(self.zero_point_impl) is not ZeroZeroPoint or type(self.int_scaling_impl) is not IntScaling:
+            return None
+        if getattr(bit_width, 'bvq_host_value', None) is None:
+            return None
+        sc = self.scaling_impl
+        runtime = None
+        if type(sc) is RuntimeStatsScaling:
+            if not sc.training:
+                return None
+            runtime = sc.runtime_stats
+            view, stats = runtime.stats_input_view_shape_impl, runtime.stats
+        elif type(sc) is StatsFromParameterScaling:
+            pls = sc.parameter_list_stats
+            if pls.extra_tracked_params_list is not None:
+                return None
+            w = pls.first_tracked_param.parameter
+            if not (w is x or (w.data_ptr() == x.data_ptr() and w.shape == x.shape
+                               and w.stride() == x.stride() and w.dtype == x.dtype)):
+                return None
+            view, stats = pls.first_tracked_param.view_shape_impl, pls.stats
+        else:
+            return None
+        min_val = sc.stats_scaling_impl.bvq_plain_min_val()
+        if min_val is None or type(stats.stats_impl) is not AbsMax:
+            return None
+        shape = tuple(stats.stats_output_shape)
+        if type(view) is OverTensorView and stats.stats_impl.stats_reduce_dim is None:
+            if shape != ():
+                return None
+            return _fused.StatsPlan(1, 1, x.numel(), shape, min_val), runtime
+        if type(view) is OverOutputChannelView and stats.stats_impl.stats_reduce_dim in (1, -1):
+            cd = view.bvq_channel_dim(x.dim())
+            if cd is None or cd < 0:
+                return None
+            # the scaling shape must broadcast against x exactly at the channel dim
+            want = tuple(x.shape[cd] if i == cd else 1 for i in range(x.dim()))
+            padded = (1,) * (x.dim() - len(shape)) + shape
+            if len(shape) > x.dim() or padded != want or x.shape[cd] == 1:
+                return None
+            outer = 1
+            for s in x.shape[:cd]:
+                outer *= s
+            inner = 1
+            for s in x.shape[cd + 1:]:
+                inner *= s
+            return _fused.StatsPlan(outer, x.shape[cd], inner, shape, min_val), runtime
+        return None
+
+    def forward(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+        bit_width = self.msb_clamp_bit_width_impl()
+        fused = self._stats_plan(x, bit_width)
+        if fused is not None:
+            sp, runtime = fused
+            iq = self.int_quant
+            int_threshold = self.int_scaling_impl(bit_width)
+            qmin, qmax = int_range_host(iq.signed, iq.narrow_range, bit_width.bvq_host_value)
+            y, scale, stat = _fused.StatsFakeQuantFn.apply(
+                x, int_threshold, sp, qmin, qmax, iq.float_to_int_impl.bvq_round_mode,
+                iq.tensor_clamp_impl.bvq_clamp_ste)
+            if runtime is not None:
+                runtime.update_running_stats(stat)
+            zero_point = self.zero_point_impl(x, scale, bit_width)
+            return y, scale, zero_point, bit_width
+        # generic orchestration (B/core/quant/int.py:157-163)
+        threshold = self.scaling_impl(x)
+        int_threshold = self.int_scaling_impl(bit_width)
+        scale = threshold / int_threshold
+        zero_point = self.zero_point_impl(x, scale, bit_width)
+        y = self.int_quant(scale, zero_point, bit_width, x)
+        return y, scale, zero_point, bit_width

@@ -1,0 +1,98 @@
+"""IntQuant: scaled, shifted, uniform integer quantizer (drop-in for B/core/quant/int_base.py:15-97).
+
+Same constructor, same `forward(scale, zero_point, bit_width, x)`, `to_int`, `min_int`, `max_int`.
+When the injected float_to_int_impl / tensor_clamp_impl are the library's own wrappers and the bit
+width is host-known, the whole chain  x/scale + zp -> round -> clamp -> (. - zp) * scale  runs as
+ONE HIP kernel (and its autograd as one more); anything else runs the same chain op by op through
+the HIP-backed straight-through ops, exactly as the reference composes it.
+"""
+import torch
+from torch import Tensor
+from torch.nn import Module
+
+import brevitas_amd.config as config
+from brevitas_amd import _native as nat
+from brevitas_amd.core.function_wrapper import RoundSte, TensorClamp
+from brevitas_amd.core.quant import _fused
+from brevitas_amd.core.quant.delay import DelayWrapper
+from brevitas_amd.function.ops import int_range_host, max_int, min_int
+
+
+class IntQuant(torch.nn.Module):
+    """
+    Args:
+        narrow_range (bool): restrict the integer range to a narrow (symmetric) one.
+        signed (bool): signed or unsigned integer range.
+        float_to_int_impl (Module): float -> integer conversion. Default: RoundSte()
+        tensor_clamp_impl (Module): clamp to [min_int, max_int]. Default: TensorClamp()
+        quant_delay_steps (int): training steps during which the input is passed through. Default: 0
+
+    Examples (B/core/quant/int_base.py:32-38):
+        >>> int_quant = IntQuant(narrow_range=True, signed=True)
+        >>> scale, zero_point, bit_width = torch.tensor(0.01), torch.tensor(0.), torch.tensor(4.)
+        >>> int_quant(scale, zero_point, bit_width, torch.Tensor([0.042, -0.053, 0.31, -0.44]))
+        tensor([ 0.0400, -0.0500,  0.0700, -0.0700])
+    """
+
+    def __init__(self, narrow_range: bool, signed: bool, float_to_int_impl: Module = RoundSte(),
+                 tensor_clamp_impl: Module = TensorClamp(), quant_delay_steps: int = 0):
+        super().__init__()
+        self.float_to_int_impl = float_to_int_impl
+        self.tensor_clamp_impl = tensor_clamp_impl
+        self.signed = signed
+        self.narrow_range = narrow_range
+        self.delay_wrapper = DelayWrapper(quant_delay_steps)
+
+    # ---- fused path ---------------------------------------------------------------------------------
+
+    def _fused_args(self, scale: Tensor, zero_point: Tensor, bit_width: Tensor, x: Tensor):
+        """(plan, qmin, qmax, round_mode, clamp_ste) if the fused kernel covers this call, else None"""
+        if not config.FUSED_PATHS:
+            return None
+        round_mode = getattr(self.float_to_int_impl, 'bvq_round_mode', None)
+        clamp_ste = getattr(self.tensor_clamp_impl, 'bvq_clamp_ste', None)
+        bw = getattr(bit_width, 'bvq_host_value', None)
+        if round_mode is None or clamp_ste is None or bw is None:
+            return None
+        p = _fused.plan(x, scale, zero_point)
+        if p is None:
+            return None
+        qmin, qmax = int_range_host(self.signed, self.narrow_range, bw)
+        return p, qmin, qmax, round_mode, clamp_ste
+
+    # ---- reference surface ----------------------------------------------------------------------------
+
+    def to_int(self, scale: Tensor, zero_point: Tensor, bit_width: Tensor, x: Tensor) -> Tensor:
+        fa = self._fused_args(scale, zero_point, bit_width, x)
+        differentiable = torch.is_grad_enabled() and any(
+            t.requires_grad for t in (x, scale, zero_point, bit_width))
+        if fa is not None and not differentiable:
+            p, qmin, qmax, round_mode, clamp_ste = fa
+            return _fused.FakeQuantFn.apply(x, scale, zero_point, p, qmin, qmax, round_mode, clamp_ste,
+                                            nat.OUT_INT)
+        # op-by-op chain (B/core/quant/int_base.py:69-75)
+        y = x / scale
+        y = y + zero_point
+        min_int_val = self.min_int(bit_width)
+        max_int_val = self.max_int(bit_width)
+        y = self.float_to_int_impl(y)
+        y = self.tensor_clamp_impl(y, min_val=min_int_val, max_val=max_int_val)
+        return y
+
+    def min_int(self, bit_width):
+        return min_int(self.signed, self.narrow_range, bit_width)
+
+    def max_int(self, bit_width):
+        return max_int(self.signed, self.narrow_range, bit_width)
+
+    def forward(self, scale: Tensor, zero_point: Tensor, bit_width: Tensor, x: Tensor) -> Tensor:
+        fa = self._fused_args(scale, zero_point, bit_width, x)
+        if fa is not None and not bit_width.requires_grad:
+            p, qmin, qmax, round_mode, clamp_ste = fa
+            y = _fused.FakeQuantFn.apply(x, scale, zero_point, p, qmin, qmax, round_mode, clamp_ste,
+                                         nat.OUT_DEQUANT)
+        else:
+            y_int = self.to_int(scale, zero_point, bit_width, x)
+            y = y_int - zero_point
+            y = y * scale
+        return self.delay_wrapper(x, y)

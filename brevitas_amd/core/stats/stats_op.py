@@ -1,0 +1,108 @@
+"""Scale statistics on the accelerated path: AbsMax and AbsMinMax (B/core/stats/stats_op.py:129-158).
+
+Forward: one streaming read of the input by the HIP reduction (no |x| temporary, no second pass).
+Backward: what autograd derives from torch.max / torch.min / torch.abs in the reference -- the
+gradient lands on the elements attaining the extremum (first one along a reduced dim, evenly over
+all ties for a whole-tensor reduction).
+"""
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from brevitas_amd import _native as nat
+
+
+def _as_rows(x: Tensor, dim: Optional[int]):
+    """-> (contiguous tensor, outer, channels, inner, output shape) for a reduction over `dim`
+    (None: everything).  The kernel keeps the middle axis of [outer, channels, inner]."""
+    if dim is None:
+        xc = x.contiguous()
+        return xc, 1, 1, xc.numel(), ()
+    dim = dim % x.dim()
+    out_shape = tuple(s for i, s in enumerate(x.shape) if i != dim)
+    if x.dim() == 2 and dim == 1:
+        xc = x.contiguous()
+        return xc, 1, x.shape[0], x.shape[1], out_shape
+    if x.dim() == 2 and dim == 0:
+        xc = x.contiguous()
+        return xc, x.shape[0], x.shape[1], 1, out_shape
+    # general case: bring the reduced axis last, flatten the kept axes (one copy, like a
+    # non-contiguous reshape in the reference)
+    xc = x.movedim(dim, -1).reshape(-1, x.shape[dim]).contiguous()
+    return xc, 1, xc.shape[0], xc.shape[1], out_shape
+
+
+class _AbsMaxFn(Function):
+
+    @staticmethod
+    def forward(ctx, x, dim):
+        xc, outer, ch, inner, out_shape = _as_rows(x, dim)
+        stat = nat.stats(nat.STAT_ABSMAX, xc.reshape(-1), outer, ch, inner)
+        ctx.layout = (outer, ch, inner, dim)
+        ctx.save_for_backward(x, stat)
+        return stat.reshape(out_shape)
+
+    @staticmethod
+    def backward(ctx, gstat):
+        x, stat = ctx.saved_tensors
+        outer, ch, inner, dim = ctx.layout
+        xc, _, _, _, _ = _as_rows(x, dim)
+        dx = nat.stat_bwd(nat.MATCH_ABS, xc.reshape(-1), stat, gstat.reshape(-1), outer, ch, inner)
+        return _unrows(dx, x, dim), None
+
+
+class _MinMaxFn(Function):
+    """returns (max, min) of x, each with the backward of torch.max / torch.min"""
+
+    @staticmethod
+    def forward(ctx, x, dim):
+        xc, outer, ch, inner, out_shape = _as_rows(x, dim)
+        raw = nat.stats(nat.STAT_MINMAX, xc.reshape(-1), outer, ch, inner)
+        ctx.layout = (outer, ch, inner, dim)
+        mx, mn = raw[:ch], raw[ch:]
+        ctx.save_for_backward(x, mx, mn)
+        return mx.reshape(out_shape), mn.reshape(out_shape)
+
+    @staticmethod
+    def backward(ctx, gmax, gmin):
+        x, mx, mn = ctx.saved_tensors
+        outer, ch, inner, dim = ctx.layout
+        xc, _, _, _, _ = _as_rows(x, dim)
+        flat = xc.reshape(-1)
+        dx = nat.stat_bwd(nat.MATCH_VALUE, flat, mx, gmax.reshape(-1), outer, ch, inner)
+        dx = nat.stat_bwd(nat.MATCH_VALUE, flat, mn, gmin.reshape(-1), outer, ch, inner, dx=dx)
+        return _unrows(dx, x, dim), None
+
+
+def _unrows(dx_flat: Tensor, x: Tensor, dim: Optional[int]) -> Tensor:
+    """inverse of _as_rows for the gradient"""
+    if dim is None or x.dim() == 2:
+        return dx_flat.reshape(x.shape)
+    dim = dim % x.dim()
+    moved_shape = tuple(s for i, s in enumerate(x.shape) if i != dim) + (x.shape[dim],)
+    return dx_flat.reshape(moved_shape).movedim(-1, dim)
+
+
+class AbsMax(torch.nn.Module):
+    """max(|x|) over the whole (1-D) input, or along `stats_reduce_dim` of a [C, K] view"""
+
+    def __init__(self, stats_reduce_dim: Optional[int] = None) -> None:
+        super().__init__()
+        self.stats_reduce_dim = stats_reduce_dim
+
+    def forward(self, x: Tensor):
+        return _AbsMaxFn.apply(x, self.stats_reduce_dim)
+
+
+class AbsMinMax(torch.nn.Module):
+    """|max(x) - min(x)| over the whole input or along `stats_reduce_dim`"""
+
+    def __init__(self, stats_reduce_dim: Optional[int] = None) -> None:
+        super().__init__()
+        self.stats_reduce_dim = stats_reduce_dim
+
+    def forward(self, x: Tensor):
+        max_val, min_val = _MinMaxFn.apply(x, self.stats_reduce_dim)
+        return torch.abs(max_val - min_val)

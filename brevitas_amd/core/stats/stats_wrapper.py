@@ -1,0 +1,94 @@
+"""Plumbing between a statistic and a scale (B/core/stats/stats_wrapper.py:19-114): reshape to the
+scaling shape, batch-norm style running average for activations, parameter tracking for weights.
+State-dict keys (`running_stats`, ...) are the reference's."""
+from typing import List, Tuple
+
+import torch
+from torch import Tensor, nn
+
+import brevitas_amd.config as config
+
+from .view_wrapper import _ViewCatParameterWrapper, _ViewParameterWrapper
+
+DEFAULT_MOMENTUM = 0.1
+SCALAR_SHAPE = ()
+
+
+class _Stats(torch.nn.Module):
+
+    def __init__(self, stats_impl: nn.Module, stats_output_shape: Tuple[int, ...]) -> None:
+        super().__init__()
+        self.stats_output_shape = stats_output_shape
+        self.stats_impl = stats_impl
+
+    def forward(self, input: Tensor) -> Tensor:
+        stats = self.stats_impl(input)
+        return stats.view(self.stats_output_shape)
+
+
+class _RuntimeStats(torch.nn.Module):
+    """training: statistic of the current batch, folded into `running_stats`; eval: the buffer"""
+
+    def __init__(self, stats_impl: nn.Module, stats_output_shape: Tuple[int, ...],
+                 stats_input_view_shape_impl: nn.Module, stats_buffer_momentum: float = DEFAULT_MOMENTUM) -> None:
+        super().__init__()
+        self.first_batch = True
+        self.stats_input_view_shape_impl = stats_input_view_shape_impl
+        self.stats = _Stats(stats_impl, stats_output_shape)
+        self.momentum = stats_buffer_momentum
+        self.register_buffer('running_stats', torch.full(stats_output_shape, 1.0))
+
+    def update_running_stats(self, out: Tensor) -> None:
+        """fold one batch statistic into the buffer (B/core/stats/stats_wrapper.py:61-66)"""
+        out = out.detach()
+        if self.first_batch:
+            self.running_stats *= out
+            self.first_batch = False
+        else:
+            self.running_stats *= (1 - self.momentum)
+            self.running_stats += self.momentum * out
+
+    def forward(self, stats_input) -> Tensor:
+        if self.training:
+            stats_input = self.stats_input_view_shape_impl(stats_input)
+            out = self.stats(stats_input)
+            self.update_running_stats(out)
+        else:
+            out = self.running_stats
+        return out
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+        running_stats_key = prefix + 'running_stats'
+        if config.IGNORE_MISSING_KEYS and running_stats_key in missing_keys:
+            missing_keys.remove(running_stats_key)
+        training_key = prefix + 'training'
+        if training_key in missing_keys:
+            missing_keys.remove(training_key)
+
+
+class _ParameterListStats(torch.nn.Module):
+    """statistic of one tracked parameter, or of several concatenated along `stats_input_concat_dim`"""
+
+    def __init__(self, stats_impl: nn.Module, stats_output_shape: Tuple[int, ...],
+                 stats_input_view_shape_impl: nn.Module, stats_input_concat_dim: int,
+                 tracked_parameter_list: List[torch.nn.Parameter]) -> None:
+        super().__init__()
+        self.stats_input_concat_dim = stats_input_concat_dim
+        self.first_tracked_param = _ViewParameterWrapper(tracked_parameter_list[0], stats_input_view_shape_impl)
+        if len(tracked_parameter_list) > 1:
+            self.extra_tracked_params_list = torch.nn.ModuleList([
+                _ViewCatParameterWrapper(param, stats_input_view_shape_impl, stats_input_concat_dim)
+                for param in tracked_parameter_list[1:]])
+        else:
+            self.extra_tracked_params_list = None
+        self.stats = _Stats(stats_impl, stats_output_shape)
+
+    def forward(self) -> torch.Tensor:
+        stats_input = self.first_tracked_param()
+        if self.extra_tracked_params_list is not None:
+            for extra_tracked_param in self.extra_tracked_params_list:
+                stats_input = extra_tracked_param(stats_input)
+        return self.stats(stats_input)

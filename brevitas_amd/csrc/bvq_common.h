@@ -75,6 +75,19 @@ template <>
 __device__ __forceinline__ float rnd<float>(float v) {
   return v;
 }
+// float16: hipcc folds  (half)(a * b)  of half-extended operands into v_fma_mixlo_f16 a, b, +0, and
+// the +0 addend turns a -0 product into +0.  The empty asm hides the producer of v from that
+// pattern match (no instruction is emitted), keeping IEEE signed zeros.
+template <>
+__device__ __forceinline__ f16_t from_f<f16_t>(float v) {
+  asm volatile("" : "+v"(v));
+  return (f16_t)v;
+}
+template <>
+__device__ __forceinline__ float rnd<f16_t>(float v) {
+  asm volatile("" : "+v"(v));
+  return (float)(f16_t)v;
+}
 
 // N-element vector of T that is loaded / stored with a single instruction
 template <typename T, int N>

@@ -52,14 +52,32 @@ int pick_vec(int max_vec, int64_t rows, int64_t row_len, const void* const* ptrs
   return vec;
 }
 
+int max_units_per_channel() {
+  static int v = [] {
+    const char* e = getenv("BVQ_MAX_UNITS_PER_CHANNEL");
+    int n = e ? atoi(e) : 0;
+    return (n >= 1 && n <= (1 << 24)) ? n : 4096;
+  }();
+  return v;
+}
+
 Tiling make_tiling(int64_t rows, int64_t row_len, int32_t channels, int vec) {
   Tiling t;
   t.rows = rows;
   t.row_len = row_len;
   t.channels = channels;
-  int64_t piece = (int64_t)default_piece_chunks() * kWave * vec;
+  const int64_t quantum = (int64_t)kWave * vec;  // one 16-byte load per lane
+  int64_t piece = (int64_t)default_piece_chunks() * quantum;
+  // keep the number of units per channel bounded: per-unit partials are combined by one workgroup
+  // per channel, and very long rows (per-tensor quantizers) otherwise produce ~1e5 partials
+  const int64_t outer = channels > 0 ? rows / channels : rows;
+  int64_t max_ppr = max_units_per_channel() / (outer > 0 ? outer : 1);
+  if (max_ppr < 1) max_ppr = 1;
+  if (row_len > piece * max_ppr) {
+    piece = (row_len + max_ppr - 1) / max_ppr;
+    piece = ((piece + quantum - 1) / quantum) * quantum;
+  }
   if (piece > row_len) {
-    // one piece per row; keep it a multiple of vec unless the row is the whole tensor's ragged end
     piece = row_len > 0 ? row_len : 1;
     piece = ((piece + vec - 1) / vec) * vec;
   }

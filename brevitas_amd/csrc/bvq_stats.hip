@@ -209,23 +209,48 @@ __global__ __launch_bounds__(kBlock) void stat_finish_kernel(const uint32_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// AbsMax backward: locate the elements that attain the maximum ("ties") and deposit the gradient.
+// Backward of the statistics: locate the elements that attain the extremum ("ties") and deposit the
+// gradient there.  MATCH_ABS: |x| == stat, deposit scaled by sgn(x) (torch.abs backward);
+// MATCH_VALUE: x == stat (torch.max / torch.min of x itself).
 // ------------------------------------------------------------------------------------------------
 // tie_info layout (int64 words):
-//   channels > 1 : first[c]  = smallest (outer*inner + i) position with |x| == stat[c]  (init: max)
+//   channels > 1 : first[c]  = smallest (outer*inner + i) position matching stat[c]  (init: max)
 //   channels == 1: [0] = number of ties (also the list cursor), [1] = unused,
 //                  [2 .. 2+kTieCap) = flat element indices of the first kTieCap ties found
 constexpr int kTieCap = 1024;
 
-template <typename T, int VEC>
+// torch.abs backward uses sgn(x): 0 at 0
+__device__ __forceinline__ float sgn_f(float v) { return (float)(0.f < v) - (float)(v < 0.f); }
+
+template <typename T, int MATCH>
+__device__ __forceinline__ bool is_tie(T v, T stat) {
+  if constexpr (MATCH == BVQ_MATCH_ABS) {
+    return abs_bits<T>(v) == abs_bits<T>(stat);
+  } else {
+    return to_f<T>(v) == to_f<T>(stat);  // -0 == +0, NaN never matches (torch: input == value)
+  }
+}
+// what a non-tie element receives in the reference: 0 * sgn(x) for AbsMax (a signed zero), +0 else
+template <typename T, int MATCH>
+__device__ __forceinline__ T zero_like(T v) {
+  if constexpr (MATCH == BVQ_MATCH_ABS) {
+    return from_f<T>(0.f * sgn_f(to_f<T>(v)));
+  } else {
+    return from_f<T>(0.f);
+  }
+}
+
+template <typename T, int VEC, int MATCH, bool WRITE_ZERO>
 __global__ __launch_bounds__(kBlock) void tie_scan_kernel(Tiling t, const void* x, const void* stat,
-                                                          unsigned long long* info, int64_t inner) {
+                                                          unsigned long long* info, void* dx,
+                                                          int64_t inner) {
   int64_t unit, start, len, row_off;
   int32_t channel;
   if (!locate(t, unit, start, len, channel, row_off)) return;
   const int lane = threadIdx.x & 63;
   const T* __restrict__ xp = reinterpret_cast<const T*>(x) + start;
-  const uint32_t sb = abs_bits<T>(reinterpret_cast<const T*>(stat)[channel]);
+  T* __restrict__ dp = reinterpret_cast<T*>(dx) + start;
+  const T sv = reinterpret_cast<const T*>(stat)[channel];
   const bool per_channel = t.channels > 1;
   // position of this unit's first element in the reference's reduction order for its channel:
   // (outer index) * inner + offset inside the row
@@ -237,9 +262,11 @@ __global__ __launch_bounds__(kBlock) void tie_scan_kernel(Tiling t, const void* 
     const int64_t e0 = i * VEC;
     if (i < nvec) {
       const vec_t<T, VEC> xv = load_vec<T, VEC>(xp + e0);
+      vec_t<T, VEC> zv;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
-        if (abs_bits<T>(xv.v[k]) == sb) {
+        zv.v[k] = zero_like<T, MATCH>(xv.v[k]);
+        if (is_tie<T, MATCH>(xv.v[k], sv)) {
           const unsigned long long pos = (unsigned long long)(pos0 + e0 + k);
           if (per_channel) {
             atomicMin(&info[channel], pos);
@@ -249,10 +276,12 @@ __global__ __launch_bounds__(kBlock) void tie_scan_kernel(Tiling t, const void* 
           }
         }
       }
+      if (WRITE_ZERO) store_vec<T, VEC>(dp + e0, zv);
     } else if (i == nvec) {
       // ragged end: lane `nvec` walks the (< VEC) leftover elements
       for (int64_t e = nvec * VEC; e < len; ++e) {
-        if (abs_bits<T>(xp[e]) == sb) {
+        if (WRITE_ZERO) dp[e] = zero_like<T, MATCH>(xp[e]);
+        if (is_tie<T, MATCH>(xp[e], sv)) {
           const unsigned long long pos = (unsigned long long)(pos0 + e);
           if (per_channel) {
             atomicMin(&info[channel], pos);
@@ -275,11 +304,17 @@ __global__ void tie_init_kernel(unsigned long long* info, int32_t channels) {
   }
 }
 
-// torch.abs backward uses sgn(x): 0 at 0
-__device__ __forceinline__ float sgn_f(float v) { return (float)(0.f < v) - (float)(v < 0.f); }
+template <typename T, int MATCH>
+__device__ __forceinline__ float deposit(float g, T xv) {
+  if constexpr (MATCH == BVQ_MATCH_ABS) {
+    return rnd<T>(g * sgn_f(to_f<T>(xv)));
+  } else {
+    return g;
+  }
+}
 
-// channels > 1: one thread per channel deposits sgn(x) * gstat[c] at first[c]
-template <typename T>
+// channels > 1: one thread per channel deposits the gradient at first[c]
+template <typename T, int MATCH>
 __global__ void tie_apply_first_kernel(const void* x, const void* gstat, const unsigned long long* info,
                                        void* dx, int64_t outer, int32_t channels, int64_t inner,
                                        int mode_add) {
@@ -292,13 +327,12 @@ __global__ void tie_apply_first_kernel(const void* x, const void* gstat, const u
   const int64_t flat = (o * channels + c) * inner + i;
   const T* xp = reinterpret_cast<const T*>(x);
   T* dp = reinterpret_cast<T*>(dx);
-  const float g = to_f<T>(reinterpret_cast<const T*>(gstat)[c]);
-  const float term = rnd<T>(g * sgn_f(to_f<T>(xp[flat])));
+  const float term = deposit<T, MATCH>(to_f<T>(reinterpret_cast<const T*>(gstat)[c]), xp[flat]);
   dp[flat] = mode_add ? from_f<T>(to_f<T>(dp[flat]) + term) : from_f<T>(term);
 }
 
-// channels == 1, ties fit the list: each tie receives sgn(x) * (gstat / count)
-template <typename T>
+// channels == 1, ties fit the list: each tie receives (gstat / count)
+template <typename T, int MATCH>
 __global__ void tie_apply_list_kernel(const void* x, const void* gstat, const unsigned long long* info,
                                       void* dx, int mode_add) {
   const unsigned long long cnt = info[0];
@@ -311,13 +345,13 @@ __global__ void tie_apply_list_kernel(const void* x, const void* gstat, const un
   for (unsigned long long k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt;
        k += (unsigned long long)gridDim.x * blockDim.x) {
     const int64_t flat = (int64_t)info[2 + k];
-    const float term = rnd<T>(share * sgn_f(to_f<T>(xp[flat])));
+    const float term = deposit<T, MATCH>(share, xp[flat]);
     dp[flat] = mode_add ? from_f<T>(to_f<T>(dp[flat]) + term) : from_f<T>(term);
   }
 }
 
 // channels == 1, more ties than the list holds (constant tensors, binarised weights): full pass
-template <typename T>
+template <typename T, int MATCH>
 __global__ __launch_bounds__(kBlock) void tie_apply_full_kernel(const void* x, const void* stat,
                                                                 const void* gstat,
                                                                 const unsigned long long* info, void* dx,
@@ -326,13 +360,12 @@ __global__ __launch_bounds__(kBlock) void tie_apply_full_kernel(const void* x, c
   if (cnt <= (unsigned long long)kTieCap) return;
   const T* xp = reinterpret_cast<const T*>(x);
   T* dp = reinterpret_cast<T*>(dx);
-  const uint32_t sb = abs_bits<T>(reinterpret_cast<const T*>(stat)[0]);
-  // (the integer count is converted to the gradient's dtype first, as torch's type promotion does)
+  const T sv = reinterpret_cast<const T*>(stat)[0];
   const float share = rnd<T>(to_f<T>(reinterpret_cast<const T*>(gstat)[0]) / rnd<T>((float)cnt));
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const T xv = xp[i];
-    if (abs_bits<T>(xv) == sb) {
-      const float term = rnd<T>(share * sgn_f(to_f<T>(xv)));
+    if (is_tie<T, MATCH>(xv, sv)) {
+      const float term = deposit<T, MATCH>(share, xv);
       dp[i] = mode_add ? from_f<T>(to_f<T>(dp[i]) + term) : from_f<T>(term);
     }
   }
@@ -391,35 +424,39 @@ static void launch_stat(int kind, const StatArgs& a, int vec, hipStream_t st) {
   }
 }
 
-template <typename T>
-static void launch_tie_scan(const Tiling& t, int vec, const void* x, const void* stat,
-                            unsigned long long* info, int64_t inner, hipStream_t st) {
+template <typename T, int MATCH, bool WZ>
+static void launch_tie_scan_v(const Tiling& t, int vec, const void* x, const void* stat,
+                              unsigned long long* info, void* dx, int64_t inner, hipStream_t st) {
   constexpr int V = elem<T>::vec;
   const dim3 grid(grid_for_units(t.units)), block(kBlock);
   if (vec == V)
-    tie_scan_kernel<T, V><<<grid, block, 0, st>>>(t, x, stat, info, inner);
+    tie_scan_kernel<T, V, MATCH, WZ><<<grid, block, 0, st>>>(t, x, stat, info, dx, inner);
   else if (vec == 2)
-    tie_scan_kernel<T, 2><<<grid, block, 0, st>>>(t, x, stat, info, inner);
+    tie_scan_kernel<T, 2, MATCH, WZ><<<grid, block, 0, st>>>(t, x, stat, info, dx, inner);
   else
-    tie_scan_kernel<T, 1><<<grid, block, 0, st>>>(t, x, stat, info, inner);
+    tie_scan_kernel<T, 1, MATCH, WZ><<<grid, block, 0, st>>>(t, x, stat, info, dx, inner);
 }
 
-template <typename T>
-static void launch_tie_apply(const void* x, const void* stat, const void* gstat,
-                             const unsigned long long* info, void* dx, int64_t outer, int64_t channels,
-                             int64_t inner, int mode_add, hipStream_t st) {
+template <typename T, int MATCH>
+static void run_stat_bwd(const Tiling& t, int vec, const void* x, const void* stat, const void* gstat,
+                         unsigned long long* info, void* dx, int64_t outer, int64_t channels,
+                         int64_t inner, int mode_add, hipStream_t st) {
+  if (mode_add)
+    launch_tie_scan_v<T, MATCH, false>(t, vec, x, stat, info, dx, inner, st);
+  else
+    launch_tie_scan_v<T, MATCH, true>(t, vec, x, stat, info, dx, inner, st);
   if (channels > 1) {
     const unsigned nb = (unsigned)((channels + 255) / 256);
-    tie_apply_first_kernel<T><<<dim3(nb), dim3(256), 0, st>>>(x, gstat, info, dx, outer,
-                                                              (int32_t)channels, inner, mode_add);
+    tie_apply_first_kernel<T, MATCH><<<dim3(nb), dim3(256), 0, st>>>(x, gstat, info, dx, outer,
+                                                                     (int32_t)channels, inner, mode_add);
   } else {
-    tie_apply_list_kernel<T><<<dim3(4), dim3(256), 0, st>>>(x, gstat, info, dx, mode_add);
+    tie_apply_list_kernel<T, MATCH><<<dim3(4), dim3(256), 0, st>>>(x, gstat, info, dx, mode_add);
     const int64_t n = outer * inner;
     int64_t nb = (n + kBlock - 1) / kBlock;
     if (nb > 2048) nb = 2048;
     // exits immediately unless the tie list overflowed
-    tie_apply_full_kernel<T><<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(x, stat, gstat, info, dx, n,
-                                                                          mode_add);
+    tie_apply_full_kernel<T, MATCH><<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(x, stat, gstat, info,
+                                                                                 dx, n, mode_add);
   }
 }
 
@@ -490,40 +527,52 @@ extern "C" int bvq_stats(int kind, int dtype, const void* x, int64_t outer, int6
   return check_launch("bvq_stats/finish");
 }
 
-extern "C" int bvq_absmax_bwd(int dtype, const void* x, const void* stat, const void* gstat, void* dx,
-                              int64_t outer, int64_t channels, int64_t inner, int mode_add,
-                              void* workspace, int64_t workspace_bytes, bvq_stream_t stream) {
-  if (bad_dtype(dtype) || outer < 0 || channels < 1 || inner < 0) {
-    set_error("bvq_absmax_bwd: bad argument");
+extern "C" int bvq_stat_bwd(int match, int dtype, const void* x, const void* stat, const void* gstat,
+                            void* dx, int64_t outer, int64_t channels, int64_t inner, int mode_add,
+                            void* workspace, int64_t workspace_bytes, bvq_stream_t stream) {
+  if (bad_dtype(dtype) || outer < 0 || channels < 1 || inner < 0 ||
+      (match != BVQ_MATCH_ABS && match != BVQ_MATCH_VALUE)) {
+    set_error("bvq_stat_bwd: bad argument");
     return BVQ_ERR_INVALID;
   }
   const int64_t n = outer * channels * inner;
   if (n == 0) return BVQ_OK;
   if (!x || !stat || !gstat || !dx || !workspace) {
-    set_error("bvq_absmax_bwd: null pointer");
+    set_error("bvq_stat_bwd: null pointer");
     return BVQ_ERR_INVALID;
   }
   const int64_t tie_words = channels > 1 ? channels : 2 + kTieCap;
   if (workspace_bytes < tie_words * (int64_t)sizeof(int64_t)) {
-    set_error("bvq_absmax_bwd: workspace too small");
+    set_error("bvq_stat_bwd: workspace too small");
     return BVQ_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* info = reinterpret_cast<unsigned long long*>(workspace);
   int vec;
-  const Tiling t = stat_tiling(dtype, x, outer, channels, inner, vec);
+  const void* ptrs[2] = {x, dx};
+  Tiling t = stat_tiling(dtype, x, outer, channels, inner, vec);
+  if (reinterpret_cast<uintptr_t>(dx) % 16 != 0 && vec > 1) {
+    vec = 1;
+    t = make_tiling(t.rows, t.row_len, t.channels, 1);
+  }
+  (void)ptrs;
   tie_init_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, st>>>(info,
                                                                                   (int32_t)channels);
-  if (!mode_add) (void)hipMemsetAsync(dx, 0, (size_t)n * dtype_size(dtype), st);
-  if (dtype == BVQ_F32) {
-    launch_tie_scan<float>(t, vec, x, stat, info, inner, st);
-    launch_tie_apply<float>(x, stat, gstat, info, dx, outer, channels, inner, mode_add, st);
-  } else if (dtype == BVQ_BF16) {
-    launch_tie_scan<bf16_t>(t, vec, x, stat, info, inner, st);
-    launch_tie_apply<bf16_t>(x, stat, gstat, info, dx, outer, channels, inner, mode_add, st);
-  } else {
-    launch_tie_scan<f16_t>(t, vec, x, stat, info, inner, st);
-    launch_tie_apply<f16_t>(x, stat, gstat, info, dx, outer, channels, inner, mode_add, st);
-  }
-  return check_launch("bvq_absmax_bwd");
+#define BVQ_RUN(T)                                                                                       \
+  do {                                                                                                   \
+    if (match == BVQ_MATCH_ABS)                                                                          \
+      run_stat_bwd<T, BVQ_MATCH_ABS>(t, vec, x, stat, gstat, info, dx, outer, channels, inner, mode_add, \
+                                     st);                                                                \
+    else                                                                                                 \
+      run_stat_bwd<T, BVQ_MATCH_VALUE>(t, vec, x, stat, gstat, info, dx, outer, channels, inner,         \
+                                       mode_add, st);                                                    \
+  } while (0)
+  if (dtype == BVQ_F32)
+    BVQ_RUN(float);
+  else if (dtype == BVQ_BF16)
+    BVQ_RUN(bf16_t);
+  else
+    BVQ_RUN(f16_t);
+#undef BVQ_RUN
+  return check_launch("bvq_stat_bwd");
 }

@@ -162,17 +162,24 @@ int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer, int64_t ch
 int bvq_stats(int kind, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
               int out_dtype, void* out, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
 
-/* Backward of AbsMax w.r.t. x, as autograd derives it from torch.max(torch.abs(x)[, dim])
- * (B/core/stats/stats_op.py:137-141):
- *   channels == 1 (full reduction): every element with |x| == stat receives sgn(x) * (gstat / #ties);
- *   channels  > 1 (max along a dim): the FIRST such element of each channel, in (outer, inner)
- *                                    order, receives sgn(x) * gstat[c].
+/* which elements attain the statistic */
+typedef enum bvq_match_kind {
+  BVQ_MATCH_ABS = 0,  /* |x| == stat, deposit scaled by sgn(x): torch.max(torch.abs(x)) (AbsMax)   */
+  BVQ_MATCH_VALUE = 1 /*  x  == stat: torch.max(x) / torch.min(x) (the two halves of AbsMinMax)    */
+} bvq_match_kind;
+
+/* Backward of a max / min statistic w.r.t. x, as autograd derives it from torch.max / torch.min
+ * (and torch.abs) in B/core/stats/stats_op.py:137-158:
+ *   channels == 1 (full reduction): every element attaining stat receives gstat / #ties;
+ *   channels  > 1 (reduction along a dim): the FIRST such element of each channel, in
+ *                                    (outer, inner) order, receives gstat[c];
+ *   MATCH_ABS additionally multiplies by sgn(x) (0 at 0), so zeros carry the sign of x.
  * mode_add == 0: dx is fully written (zeros elsewhere); mode_add == 1: the terms are added in place
- * to an existing dx (used by the fused quantizer backward; one streaming read of x, no write pass).
+ * to an existing dx (used by the fused quantizer backward: one streaming read of x, no write pass).
  * stat, gstat and dx have dtype `dtype`.  workspace: bvq_stats_workspace_bytes(ABSMAX,...) bytes. */
-int bvq_absmax_bwd(int dtype, const void* x, const void* stat, const void* gstat, void* dx,
-                   int64_t outer, int64_t channels, int64_t inner, int mode_add, void* workspace,
-                   int64_t workspace_bytes, bvq_stream_t stream);
+int bvq_stat_bwd(int match, int dtype, const void* x, const void* stat, const void* gstat, void* dx,
+                 int64_t outer, int64_t channels, int64_t inner, int mode_add, void* workspace,
+                 int64_t workspace_bytes, bvq_stream_t stream);
 
 /* ---- fused affine quantize / dequantize (seam 2: IntQuant) ---------------------------------- */
 
@@ -193,6 +200,7 @@ int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* desc);
  *   dx = dt / scale                                              (dtype x_dtype)
  *   dscale[c] = sum g*(t_clamped - zp)  -  sum dt * ((x/scale)/scale)     (float32, nullable)
  *   dzp[c]    = sum dt - sum g*scale                                      (float32, nullable)
+ * dscale / dzp have `channels` elements when scale OR zero-point is per-channel, else one.
  * One read of g, one read of x, one write of dx; the per-channel sums ride on the same reads and
  * are combined in a fixed order (bit-reproducible run to run). */
 int bvq_fakequant_bwd(const bvq_quant_desc* desc, const void* g, const void* x, const void* scale,

@@ -1,0 +1,319 @@
+"""GPU parity of the module surface (seam 2) against golden vectors produced by the reference's own
+modules: the resolved graphs of the named quantizers are rebuilt here with
+brevitas_amd's same-named classes, same constructor arguments, and must give the reference's
+outputs, scales, running statistics, state-dict keys and gradients.
+
+Bars: y, scale, running statistics and dx are bit-exact, except the few dx elements that receive
+the statistic's gradient (arg-max deposit), whose value contains a reduced sum (tolerance below);
+gradients of learned scale parameters are reduced sums too (tolerance below).
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}
+# reduced sums: the reference rounds each product and the sum to the compute dtype
+SUM_RTOL = {'f32': 2e-5, 'bf16': 2.0 ** -6, 'f16': 2.0 ** -9}
+
+
+@pytest.fixture(autouse=True)
+def cpu_scalar_semantics(monkeypatch):
+    """the golden vectors were produced by torch CPU kernels: a 0-dim float32 scale next to a bf16
+    tensor keeps its float32 value there (see include/bvq.h, bvq_scalar_mode)"""
+    import brevitas_amd.config as config
+    monkeypatch.setattr(config, 'SCALAR_OPERAND_MODE', 'cpu')
+
+
+def mods():
+    from brevitas_amd.core.bit_width import BitWidthConst
+    from brevitas_amd.core.function_wrapper import (OverOutputChannelView, OverTensorView, RoundSte, TensorClamp,
+                                                    TensorClampSte)
+    from brevitas_amd.core.quant import IntQuant, RescalingIntQuant
+    from brevitas_amd.core.restrict_val import FloatRestrictValue
+    from brevitas_amd.core.scaling import (ConstScaling, IntScaling, ParameterFromRuntimeStatsScaling,
+                                           ParameterScaling, RuntimeStatsScaling, StatsFromParameterScaling)
+    from brevitas_amd.core.stats import AbsMax
+    from brevitas_amd.core.zero_point import ZeroZeroPoint
+    return locals()
+
+
+def weight_quant(w, bit_width):
+    m = mods()
+    shape = (w.shape[0],) + (1,) * (w.dim() - 1)
+    return m['RescalingIntQuant'](
+        m['IntQuant'](narrow_range=True, signed=True, float_to_int_impl=m['RoundSte'](),
+                      tensor_clamp_impl=m['TensorClampSte']()),
+        m['StatsFromParameterScaling'](m['AbsMax'](1), m['OverOutputChannelView'](None), 1, [w],
+                                       m['FloatRestrictValue'](), shape, affine_rescaling=False,
+                                       scaling_min_val=1e-10),
+        m['IntScaling'](signed=True, narrow_range=True), m['ZeroZeroPoint'](), m['BitWidthConst'](bit_width))
+
+
+def _act_parts(pc):
+    m = mods()
+    if pc is None:
+        return m['OverTensorView'](), m['AbsMax'](), ()
+    return m['OverOutputChannelView']((1, 0, 2, 3)), m['AbsMax'](1), (1, pc, 1, 1)
+
+
+def act_quant_runtime_stats(pc):
+    m = mods()
+    view, stats, shape = _act_parts(pc)
+    return m['RescalingIntQuant'](
+        m['IntQuant'](narrow_range=False, signed=True, float_to_int_impl=m['RoundSte'](),
+                      tensor_clamp_impl=m['TensorClamp']()),
+        m['RuntimeStatsScaling'](stats, view, m['FloatRestrictValue'](), shape, affine_rescaling=False,
+                                 scaling_stats_momentum=0.1, scaling_min_val=1e-10),
+        m['IntScaling'](signed=True, narrow_range=False), m['ZeroZeroPoint'](), m['BitWidthConst'](8))
+
+
+def act_quant_param_from_stats(steps, pc):
+    m = mods()
+    view, stats, shape = _act_parts(pc)
+    return m['RescalingIntQuant'](
+        m['IntQuant'](narrow_range=False, signed=True, float_to_int_impl=m['RoundSte'](),
+                      tensor_clamp_impl=m['TensorClamp']()),
+        m['ParameterFromRuntimeStatsScaling'](steps, stats, view, shape, m['FloatRestrictValue'](), 0.1, 1e-10),
+        m['IntScaling'](signed=True, narrow_range=False), m['ZeroZeroPoint'](), m['BitWidthConst'](8))
+
+
+def to_np(t):
+    t = t.detach().cpu().contiguous()
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.view(torch.int16).numpy().view(np.uint16)
+    return t.numpy()
+
+
+def assert_bits(t, c, name):
+    want = c.arr(name)
+    got = to_np(t).reshape(want.shape)
+    assert G.same_bits(got, want, c['dtypes'][name]), (name, G.mismatch_report(got, want, 0))
+
+
+def assert_dx(dx, c, x, deposit_positions=None):
+    """bit-exact except at the positions that receive a reduced sum, which get a tolerance"""
+    want = c.f32('dx').reshape(-1)
+    got = dx.detach().float().cpu().numpy().reshape(-1)
+    dn = c['dtypes']['dx']
+    gotb, wantb = to_np(dx).reshape(-1), c.arr('dx').reshape(-1)
+    if dn == 'f32':
+        same = (gotb.view(np.uint32) == wantb.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    else:
+        same = gotb == wantb
+    bad = np.nonzero(~same)[0]
+    if deposit_positions is None:
+        assert bad.size == 0, G.mismatch_report(gotb, wantb, 0)
+        return
+    assert set(bad.tolist()) <= set(deposit_positions), (bad.tolist(), sorted(deposit_positions))
+    # the deposited value is sgn * sum_k g*(q - w/s) / int_max: a sum over the channel
+    scale = max(1.0, float(np.abs(want).max()))
+    for i in bad:
+        assert abs(got[i] - want[i]) <= SUM_RTOL[dn] * 64 * scale, (i, got[i], want[i])
+
+
+GRAPHS = G.load('quant_graphs')
+
+
+def sel(graph):
+    cs = [c for c in GRAPHS if c['graph'] == graph]
+    return pytest.mark.parametrize('c', cs, ids=G.ids(cs, ['tag', 'dtype', 'step']))
+
+
+def argmax_positions(x, chdim):
+    """flat indices of the first |x| maximum of every channel (dim `chdim`), or of all maxima"""
+    xf = x.detach().float().cpu()
+    if chdim is None:
+        m = xf.abs().max()
+        return set(torch.nonzero(xf.abs().reshape(-1) == m).reshape(-1).tolist())
+    pos = set()
+    perm = [chdim] + [i for i in range(xf.dim()) if i != chdim]
+    xp = xf.permute(perm).contiguous()
+    flat_idx = torch.arange(xf.numel()).reshape(xf.shape).permute(perm).contiguous().reshape(xp.shape[0], -1)
+    a = xp.reshape(xp.shape[0], -1).abs()
+    for ch in range(a.shape[0]):
+        k = int(torch.nonzero(a[ch] == a[ch].max())[0])
+        pos.add(int(flat_idx[ch, k]))
+    return pos
+
+
+@sel('weight_per_channel')
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'generic'])
+def test_weight_per_channel(c, fused, monkeypatch):
+    """Int8WeightPerChannelFloat / Int4 (configs 2 and 5): stats-scaled weights"""
+    import brevitas_amd.config as config
+    monkeypatch.setattr(config, 'FUSED_PATHS', fused)
+    w = torch.nn.Parameter(c.torch('x', DEV))
+    q = weight_quant(w, c['bit_width']).to(DEV)
+    y, scale, zp, bw = q(w)
+    assert_bits(y, c, 'y')
+    assert_bits(scale, c, 'scale')
+    assert float(zp) == 0.0 and float(bw) == c['bit_width']
+    y.backward(c.torch('g', DEV))
+    assert_dx(w.grad, c, w, argmax_positions(w, 0))
+
+
+@sel('act_runtime_stats')
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'generic'])
+def test_act_runtime_stats(c, fused, monkeypatch):
+    """RuntimeStatsScaling(AbsMax): batch statistic in training (+ running average), buffer in eval"""
+    import brevitas_amd.config as config
+    monkeypatch.setattr(config, 'FUSED_PATHS', fused)
+    key = (c['tag'], c['dtype'])
+    series = [k for k in GRAPHS if k['graph'] == 'act_runtime_stats' and (k['tag'], k['dtype']) == key]
+    q = act_quant_runtime_stats(c['channels']).to(DEV)
+    q.train()
+    # replay the steps before this one to bring the running statistics to the same state
+    for prev in series:
+        if prev['step'] >= c['step']:
+            break
+        q(prev.torch('x', DEV))
+    q.train(c['training'])
+    x = c.torch('x', DEV).requires_grad_(True)
+    y, scale, zp, bw = q(x)
+    assert_bits(y, c, 'y')
+    assert_bits(scale, c, 'scale')
+    assert_bits(q.scaling_impl.runtime_stats.running_stats, c, 'running_stats')
+    y.backward(c.torch('g', DEV))
+    dep = argmax_positions(x, 1 if c['channels'] else None) if c['training'] else None
+    assert_dx(x.grad, c, x, dep)
+
+
+@sel('act_param_from_stats')
+def test_act_param_from_stats(c):
+    """Int8ActPerTensorFloat with MAX statistics: collection phase, hand-over, learned parameter"""
+    key = (c['tag'], c['dtype'])
+    series = [k for k in GRAPHS if k['graph'] == 'act_param_from_stats' and (k['tag'], k['dtype']) == key]
+    q = act_quant_param_from_stats(2, c['channels']).to(DEV)
+    q.train()
+    for prev in series:
+        if prev['step'] >= c['step']:
+            break
+        q(prev.torch('x', DEV))
+    x = c.torch('x', DEV).requires_grad_(True)
+    q.zero_grad()
+    y, scale, zp, bw = q(x)
+    si = q.scaling_impl
+    assert si.counter == c['counter']
+    assert_bits(y, c, 'y')
+    assert_bits(scale, c, 'scale')
+    assert_bits(si.buffer, c, 'buffer')
+    assert_bits(si.value, c, 'value')
+    y.backward(c.torch('g', DEV))
+    collecting = c['step'] < 2
+    assert_dx(x.grad, c, x, argmax_positions(x, 1 if c['channels'] else None) if collecting else None)
+    if c.has('dvalue'):
+        want = c.f32('dvalue').reshape(-1)
+        got = si.value.grad.detach().float().cpu().numpy().reshape(-1)
+        mag = float(np.abs(c.f32('g')).sum()) * 128 * 2 / max(1, want.size)
+        np.testing.assert_allclose(got, want, rtol=0, atol=SUM_RTOL[c['dtypes']['y']] * mag)
+
+
+def test_param_from_stats_state_dict_keys():
+    """the state dict of a quantizer that finished collecting has exactly the reference's keys"""
+    for c in [k for k in GRAPHS if k['graph'] == 'act_param_from_stats_state_dict']:
+        key = (c['tag'], c['dtype'])
+        series = [k for k in GRAPHS if k['graph'] == 'act_param_from_stats' and (k['tag'], k['dtype']) == key]
+        pc = series[0]['channels']
+        q = act_quant_param_from_stats(2, pc).to(DEV)
+        q.train()
+        for s in series:
+            q(s.torch('x', DEV))
+        sd = q.state_dict()
+        assert sorted(sd.keys()) == c['keys']
+        for k in c['keys']:
+            assert_bits(sd[k], c, k.replace('.', '__'))
+        # loading it into a fresh quantizer skips collection (B/core/scaling/standalone.py:266-298)
+        q2 = act_quant_param_from_stats(2, pc).to(DEV)
+        q2.load_state_dict(sd)
+        assert q2.scaling_impl.counter == 3
+
+
+@sel('act_parameter_scale')
+def test_act_parameter_scale(c):
+    """steady state of Int8ActPerTensorFloat: learned per-tensor scale (ParameterScaling)"""
+    m = mods()
+    q = m['RescalingIntQuant'](
+        m['IntQuant'](narrow_range=False, signed=True, float_to_int_impl=m['RoundSte'](),
+                      tensor_clamp_impl=m['TensorClamp']()),
+        m['ParameterScaling'](3.0, scaling_shape=None, restrict_scaling_impl=m['FloatRestrictValue'](),
+                              scaling_min_val=1e-10),
+        m['IntScaling'](signed=True, narrow_range=False), m['ZeroZeroPoint'](), m['BitWidthConst'](8))
+    if c['module_cast']:
+        q = q.to(DT[c['dtype']])
+    q = q.to(DEV)
+    x = c.torch('x', DEV).requires_grad_(True)
+    y, scale, zp, bw = q(x)
+    assert_bits(y, c, 'y')
+    assert_bits(scale, c, 'scale')
+    y.backward(c.torch('g', DEV))
+    assert_dx(x.grad, c, x)
+    want = c.f32('dvalue').reshape(-1)
+    got = q.scaling_impl.value.grad.detach().float().cpu().numpy().reshape(-1)
+    mag = float(np.abs(c.f32('g')).sum()) * 128 * 2
+    np.testing.assert_allclose(got, want, rtol=0, atol=SUM_RTOL[c['dtypes']['y']] * mag)
+
+
+def test_const_scale_doctest():
+    """B/core/quant/int.py:113-134"""
+    m = mods()
+    c = [k for k in GRAPHS if k['graph'] == 'const_scale_doctest'][0]
+    q = m['RescalingIntQuant'](m['IntQuant'](narrow_range=True, signed=True), m['ConstScaling'](0.1),
+                               m['IntScaling'](signed=True, narrow_range=True), m['ZeroZeroPoint'](),
+                               m['BitWidthConst'](4)).to(DEV)
+    y, scale, zp, bw = q(c.torch('x', DEV))
+    assert_bits(y, c, 'y')
+    assert_bits(scale, c, 'scale')
+    assert torch.allclose(y.cpu(), torch.tensor([0.0429, -0.0571, 0.1000, -0.1000]), atol=5e-5)
+    assert abs(float(scale) - 0.0143) < 5e-5 and float(zp) == 0.0 and float(bw) == 4.0
+
+
+def test_int_quant_doctest_and_tensor_bit_width():
+    """B/core/quant/int_base.py:32-38; a plain tensor bit width (not host-known) takes the op-by-op
+    chain and must agree with the fused kernel"""
+    m = mods()
+    iq = m['IntQuant'](narrow_range=True, signed=True).to(DEV)
+    scale, zp = torch.tensor(0.01, device=DEV), torch.tensor(0., device=DEV)
+    x = torch.tensor([0.042, -0.053, 0.31, -0.44], device=DEV)
+    y_generic = iq(scale, zp, torch.tensor(4., device=DEV), x)
+    bw = m['BitWidthConst'](4).to(DEV)()
+    y_fused = iq(scale, zp, bw, x)
+    assert torch.equal(y_generic, y_fused)
+    assert torch.allclose(y_fused.cpu(), torch.tensor([0.04, -0.05, 0.07, -0.07]), atol=5e-5)
+    assert torch.equal(iq.to_int(scale, zp, bw, x).cpu(), torch.tensor([4., -5., 7., -7.]))
+    assert float(iq.min_int(bw)) == -7.0 and float(iq.max_int(bw)) == 7.0
+
+
+INT_QUANT = G.load('int_quant')
+
+
+@pytest.mark.parametrize('c', INT_QUANT, ids=G.ids(INT_QUANT, ['x_dtype', 'layout', 'round', 'clamp', 'bit_width']))
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'generic'])
+def test_int_quant_module_golden(c, fused, monkeypatch):
+    """IntQuant module (fused kernel and op-by-op chain) against the reference's IntQuant"""
+    import brevitas_amd.config as config
+    from brevitas_amd.core.function_wrapper import (CeilSte, DPURoundSte, FloorSte, RoundSte, RoundToZeroSte,
+                                                    TensorClamp, TensorClampSte)
+    monkeypatch.setattr(config, 'FUSED_PATHS', fused)
+    m = mods()
+    rimpl = {'round': RoundSte, 'floor': FloorSte, 'ceil': CeilSte, 'rtz': RoundToZeroSte, 'dpu': DPURoundSte}
+    iq = m['IntQuant'](narrow_range=c['narrow'], signed=c['signed'], float_to_int_impl=rimpl[c['round']](),
+                       tensor_clamp_impl=TensorClampSte() if c['clamp'] == 'ste' else TensorClamp()).to(DEV)
+    bw = m['BitWidthConst'](c['bit_width']).to(DEV)()
+    x = c.torch('x', DEV).requires_grad_(True)
+    scale = c.torch('scale', DEV).requires_grad_(True)
+    zp = c.torch('zp', DEV).requires_grad_(True)
+    if not fused and c.arr('scale').size == 1 and c['dtypes']['scale'] == 'f32' and c['dtypes']['x'] != 'f32':
+        pytest.skip("the op-by-op chain runs torch's device kernels, which round a 0-dim float32 scale to "
+                    "the tensor dtype first; the golden vectors hold the CPU kernels' behaviour")
+    y = iq(scale, zp, bw, x)
+    assert_bits(y, c, 'y')
+    with torch.no_grad():
+        assert_bits(iq.to_int(scale, zp, bw, x), c, 'y_int')
+    y.backward(c.torch('g', DEV))
+    assert_dx(x.grad, c, x)
+    assert scale.grad is not None and scale.grad.shape == scale.shape and scale.grad.dtype == scale.dtype
+    assert zp.grad is not None and zp.grad.shape == zp.shape

@@ -1,0 +1,56 @@
+"""Developer microbenchmark of the raw C-ABI kernels (not the judged bench; see bench.py)."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, '.')
+from brevitas_amd import _native as nat  # noqa: E402
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / iters
+
+
+def main():
+    dev = 'cuda:0'
+    N, C, H, W = 256, 512, 56, 56
+    n = N * C * H * W
+    print(torch.cuda.get_device_name(0), 'elements', n)
+    for dt, name in ((torch.bfloat16, 'bf16'), (torch.float32, 'f32')):
+        x = torch.randn(N, C, H, W, device=dev, dtype=dt).reshape(-1)
+        g = torch.randn(N, C, H, W, device=dev, dtype=dt).reshape(-1)
+        b = x.element_size()
+        # device copy as the achievable-bandwidth yardstick
+        y = torch.empty_like(x)
+        t = timeit(lambda: y.copy_(x))
+        print('%s copy           %.3f ms  %.2f TB/s' % (name, t, 2 * b * n / t / 1e9))
+        for tag, ch in (('per-tensor', 1), ('per-channel', C)):
+            outer, inner = (N, H * W) if ch > 1 else (1, n)
+            t = timeit(lambda: nat.stats(nat.STAT_ABSMAX, x, outer, ch, inner))
+            print('%s absmax %-11s %.3f ms  %.2f TB/s' % (name, tag, t, b * n / t / 1e9))
+            stat = nat.stats(nat.STAT_ABSMAX, x, outer, ch, inner)
+            scale = (stat.float().clamp_min(1e-10) / 128.0).to(dt)
+            zp = torch.zeros(1, device=dev)
+            d = nat.QuantDesc(outer, ch, inner, nat.dtype_code(dt), nat.dtype_code(dt), nat.dtype_code(dt), 0,
+                              int(ch > 1), 0, -128.0, 127.0, 0, 0, 0, 0)
+            t = timeit(lambda: nat.fakequant_fwd(d, x, scale, zp))
+            print('%s fwd    %-11s %.3f ms  %.2f TB/s' % (name, tag, t, 2 * b * n / t / 1e9))
+            t = timeit(lambda: nat.fakequant_bwd(d, g, x, scale, zp, True, False))
+            print('%s bwd    %-11s %.3f ms  %.2f TB/s (with dscale)' % (name, tag, t, 3 * b * n / t / 1e9))
+            t = timeit(lambda: nat.fakequant_bwd(d, g, x, scale, zp, False, False))
+            print('%s bwd    %-11s %.3f ms  %.2f TB/s (dx only)' % (name, tag, t, 3 * b * n / t / 1e9))
+        del x, g, y
+
+
+if __name__ == '__main__':
+    main()
