@@ -29,7 +29,7 @@ _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 EXPORTS = (
     'bvq_abi_version', 'bvq_last_error', 'bvq_unary', 'bvq_scalar_clamp', 'bvq_tensor_clamp',
     'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
-    'bvq_stat_bwd', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
+    'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
 
 
 class QuantDesc(ctypes.Structure):
@@ -67,7 +67,10 @@ def _load():
         'bvq_stat_bwd': (i32, [i32, i32, vp, vp, vp, vp, i64, i64, i64, i32, vp, i64, vp]),
         'bvq_fakequant_fwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp]),
         'bvq_fakequant_bwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
-        'bvq_fakequant_bwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+        'bvq_tie_info_bytes': (i64, [i64]),
+        'bvq_stat_tie_scan': (i32, [i32, i32, vp, vp, i64, i64, i64, vp, vp, vp]),
+        'bvq_stat_tie_apply': (i32, [i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
+        'bvq_fakequant_bwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -254,13 +257,47 @@ def fakequant_fwd(desc, x, scale, zp, want_codes=False):
     return (y, codes) if want_codes else y
 
 
-def fakequant_bwd(desc, g, x, scale, zp, need_dscale, need_dzp):
-    dev = require_device(g, x, scale, zp)
+def tie_info_buffer(channels, device):
+    nbytes = int(lib.bvq_tie_info_bytes(int(channels)))
+    return torch.empty(nbytes // 8, dtype=torch.int64, device=device)
+
+
+def stat_tie_scan(match, x, stat, outer, channels, inner, dx_zero_fill=None):
+    """record which elements of x attain `stat`; returns the tie_info buffer (int64, device)"""
+    dev = require_device(x, stat, dx_zero_fill)
+    assert x.is_contiguous()
+    stat = stat.to(x.dtype).contiguous()
+    info = tie_info_buffer(channels, dev)
+    with torch.cuda.device(dev):
+        check(lib.bvq_stat_tie_scan(match, dtype_code(x.dtype), ptr(x), ptr(stat), outer, channels, inner,
+                                    ptr(dx_zero_fill), ptr(info), stream_ptr(dev)), 'bvq_stat_tie_scan')
+    return info
+
+
+def stat_tie_apply(match, x, stat, gstat, info, dx, outer, channels, inner, mode_add, total_ties=None):
+    dev = require_device(x, stat, gstat, info, dx, total_ties)
+    assert x.is_contiguous() and dx.is_contiguous() and dx.dtype == x.dtype
+    stat = stat.to(x.dtype).contiguous()
+    gstat = gstat.to(x.dtype).contiguous()
+    with torch.cuda.device(dev):
+        check(lib.bvq_stat_tie_apply(match, dtype_code(x.dtype), ptr(x), ptr(stat), ptr(gstat), ptr(info),
+                                     ptr(total_ties), ptr(dx), outer, channels, inner, int(mode_add),
+                                     stream_ptr(dev)), 'bvq_stat_tie_apply')
+    return dx
+
+
+def fakequant_bwd(desc, g, x, scale, zp, need_dscale, need_dzp, tie_stat=None):
+    """-> (dx, dscale, dzp[, tie_info]); tie_stat: abs-max statistic whose ties are recorded on the fly"""
+    dev = require_device(g, x, scale, zp, tie_stat)
     dx = torch.empty_like(x)
     pc = (desc.scale_per_channel or desc.zp_per_channel) and desc.channels > 1
     nsum = int(desc.channels) if pc else 1
     ds = torch.empty(nsum, dtype=torch.float32, device=dev) if need_dscale else None
     dz = torch.empty(nsum, dtype=torch.float32, device=dev) if need_dzp else None
+    info = None
+    if tie_stat is not None:
+        tie_stat = tie_stat.to(x.dtype).contiguous()
+        info = tie_info_buffer(desc.channels, dev)
     ws = None
     wsb = 0
     if need_dscale or need_dzp:
@@ -272,7 +309,10 @@ def fakequant_bwd(desc, g, x, scale, zp, need_dscale, need_dzp):
         if _timer is not None:
             _timer.before('bvq_fakequant_bwd')
         check(lib.bvq_fakequant_bwd(ctypes.byref(desc), ptr(g), ptr(x), ptr(scale), ptr(zp), ptr(dx), ptr(ds),
-                                    ptr(dz), ptr(ws), wsb, stream_ptr(dev)), 'bvq_fakequant_bwd')
+                                    ptr(dz), ptr(tie_stat), ptr(info), ptr(ws), wsb, stream_ptr(dev)),
+              'bvq_fakequant_bwd')
         if _timer is not None:
             _timer.after('bvq_fakequant_bwd')
+    if tie_stat is not None:
+        return dx, ds, dz, info
     return dx, ds, dz

@@ -138,10 +138,16 @@ class StatsFakeQuantFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste):
+    def forward(ctx, x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, group=None):
         xc = x.contiguous()
         flat = xc.reshape(-1)
-        stat = nat.stats(nat.STAT_ABSMAX, flat, sp.outer, sp.channels, sp.inner)
+        if group is None:
+            stat = nat.stats(nat.STAT_ABSMAX, flat, sp.outer, sp.channels, sp.inner)
+        else:
+            # batch-sharded tensor: the statistic of the whole batch is the max over the shards
+            from brevitas_amd.distributed import sync_stat_max
+            stat32 = nat.stats(nat.STAT_ABSMAX, flat, sp.outer, sp.channels, sp.inner, out_f32=True)
+            stat = sync_stat_max(stat32, group).to(x.dtype)
         # _StatsScaling with float restriction: scalar_clamp_min_ste (B/core/restrict_val.py:22-42)
         thr = nat.scalar_clamp(stat, sp.min_val, None) if sp.min_val else stat
         # RescalingIntQuant.forward: scale = threshold / int_threshold (B/core/quant/int.py:160),
@@ -156,6 +162,7 @@ class StatsFakeQuantFn(Function):
         y = nat.fakequant_fwd(desc, xc, sc, zp.reshape(-1))
         ctx.desc = desc
         ctx.sp = sp
+        ctx.group = group
         ctx.save_for_backward(xc, scale, zp, stat, int_threshold)
         stat_out = stat.view(sp.scaling_shape)
         ctx.mark_non_differentiable(stat_out)
@@ -167,12 +174,22 @@ class StatsFakeQuantFn(Function):
         desc, sp = ctx.desc, ctx.sp
         ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
         gy = gy.to(ct).contiguous()
-        dx, ds, _ = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), True, False)
+        # one pass: dx, the scale-gradient sums and the positions attaining the statistic
+        dx, ds, _, ties = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), True,
+                                            False, tie_stat=stat)
+        total_ties = None
+        if ctx.group is not None:
+            # sum the shards' partial sums, and agree on which shard deposits the statistic's gradient
+            from brevitas_amd.distributed import sync_backward
+            if gscale is not None:
+                ds = ds + gscale.reshape(-1).to(ds.dtype)
+                gscale = None
+            ds, ties, total_ties = sync_backward(ds, ties, sp.channels, ctx.group)
         ds = _reduce_like(ds, scale)
         if gscale is not None:
             ds = ds + gscale
         # scale = thr / int_threshold  ->  dthr = dscale / int_threshold ; clamp_min_ste passes it on
         dstat = (ds / int_threshold).to(stat.dtype).reshape(-1).contiguous()
-        nat.stat_bwd(nat.MATCH_ABS, xc.reshape(-1), stat, dstat, sp.outer, sp.channels, sp.inner,
-                     dx=dx.reshape(-1))
-        return dx, None, None, None, None, None, None
+        nat.stat_tie_apply(nat.MATCH_ABS, xc.reshape(-1), stat, dstat, ties, dx.reshape(-1), sp.outer,
+                           sp.channels, sp.inner, mode_add=True, total_ties=total_ties)
+        return dx, None, None, None, None, None, None, None

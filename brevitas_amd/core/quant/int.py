@@ -117,9 +117,11 @@ class RescalingIntQuant(torch.nn.Module):
             iq = self.int_quant
             int_threshold = self.int_scaling_impl(bit_width)
             qmin, qmax = int_range_host(iq.signed, iq.narrow_range, bit_width.bvq_host_value)
+            # a batch-sharded activation (brevitas_amd.distributed.shard_over_batch); weights are replicated
+            group = getattr(self, 'bvq_shard_group', None) if runtime is not None else None
             y, scale, stat = _fused.StatsFakeQuantFn.apply(
                 x, int_threshold, sp, qmin, qmax, iq.float_to_int_impl.bvq_round_mode,
-                iq.tensor_clamp_impl.bvq_clamp_ste)
+                iq.tensor_clamp_impl.bvq_clamp_ste, group)
             if runtime is not None:
                 runtime.update_running_stats(stat)
             zero_point = self.zero_point_impl(x, scale, bit_width)

@@ -2,10 +2,12 @@
 //
 // Replaces the ~9 full-tensor ATen passes of IntQuant.forward (B/core/quant/int_base.py:63-97)
 // with one read of x and one write of y, and the ~8 passes autograd runs for its backward with one
-// read of g, one read of x and one write of dx (the per-channel scale / zero-point gradient sums
-// ride on the same reads).  HBM-bound: algorithmic bytes per element are
+// read of g, one read of x and one write of dx (the per-channel scale / zero-point gradient sums,
+// and the search for the elements that attain the abs-max statistic, ride on the same reads).
+// HBM-bound: algorithmic bytes per element are
 //   forward  sizeof(x) + sizeof(y)          backward  sizeof(g) + sizeof(x) + sizeof(dx).
 #include "bvq_quant_math.h"
+#include "bvq_ties.h"
 
 namespace bvq {
 
@@ -17,21 +19,27 @@ struct QuantArgs {
   void* y;          // fwd: output; bwd: dx
   int32_t* codes;   // fwd only, nullable
   const void* g;    // bwd only
-  float* ds_part;   // bwd only, per-unit partial of dscale (nullable)
-  float* dzp_part;  // bwd only, per-unit partial of dzp (nullable)
+  float* ds_part;   // bwd only, per-unit partial of dscale
+  float* dzp_part;  // bwd only, per-unit partial of dzp
+  const void* tie_stat;          // bwd only: abs-max statistic (dtype of x) whose ties are recorded
+  unsigned long long* tie_info;  // bwd only (bvq_ties.h)
+  int64_t inner;                 // bwd/ties: elements per row of the [outer, channels, inner] view
   float qmin, qmax;
   int32_t scale_dtype, zp_dtype;
   int32_t scale_pc, zp_pc;
   int32_t scalar_cast;
   int32_t clamp_ste;
   int32_t out_int;
+  int32_t round_mode;
 };
 
 constexpr int kUnroll = 4;  // 16-byte loads in flight per lane before arithmetic starts
 
 struct UnitInfo {
-  int64_t start;  // first element
-  int64_t len;    // elements in this unit
+  int64_t start;    // first element
+  int64_t len;      // elements in this unit
+  int64_t row;      // (outer, channel) row
+  int64_t row_off;  // offset of the unit inside its row
   int32_t channel;
   bool valid;
 };
@@ -42,18 +50,17 @@ __device__ __forceinline__ UnitInfo locate_unit(const Tiling& t) {
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   u.valid = unit < t.units;
   if (!u.valid) {
-    u.start = 0;
-    u.len = 0;
+    u.start = u.len = u.row = u.row_off = 0;
     u.channel = 0;
     return u;
   }
-  const int64_t row = unit / t.ppr;
-  const int64_t piece = unit - row * t.ppr;
-  const int64_t off = piece * t.piece_len;
-  u.start = row * t.row_len + off;
-  const int64_t rest = t.row_len - off;
+  u.row = unit / t.ppr;
+  const int64_t piece = unit - u.row * t.ppr;
+  u.row_off = piece * t.piece_len;
+  u.start = u.row * t.row_len + u.row_off;
+  const int64_t rest = t.row_len - u.row_off;
   u.len = rest < t.piece_len ? rest : t.piece_len;
-  u.channel = (int32_t)(row % t.channels);
+  u.channel = (int32_t)(u.row % t.channels);
   return u;
 }
 
@@ -68,22 +75,67 @@ __device__ __forceinline__ void load_scale_zp(const QuantArgs& a, int32_t channe
   }
 }
 
+template <typename CT, int RM>
+__device__ __forceinline__ float do_round(float t, int mode) {
+  if constexpr (RM == kAnyRM) {
+    return round_any<CT>(t, mode);
+  } else {
+    return round_op<CT, RM>(t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// division by the (wave-uniform) scale
+// ------------------------------------------------------------------------------------------------
+// DivExact: IEEE division, always right.
+// DivBf16 : a * (1/s) for a bf16 quotient of bf16 operands.  The reference computes
+//           RN_bf16(RN_f32(a / s)).  With a and s both bf16 values (8-bit significands) the exact
+//           quotient is never closer than 2^-17 (relative) to a bf16 rounding boundary and never ON
+//           one (a = m*s with m a 9-bit odd-ended midpoint needs >= 9 significant bits), while
+//           a * RN_f32(1/s) is within 2^-23 of it: both round to the same bf16.  Used only when the
+//           scale is a bf16 value in [2^-14, 2^14] (wave-uniform check); tests/test_fastdiv_exact.py
+//           verifies the claim exhaustively over every bf16 numerator.
+struct DivExact {
+  float s;
+  __device__ __forceinline__ float operator()(float a) const { return a / s; }
+};
+struct DivBf16 {
+  float r;
+  __device__ __forceinline__ float operator()(float a) const { return a * r; }
+};
+
+__device__ __forceinline__ bool bf16_fast_ok(float s, float z) {
+  const uint32_t sb = __builtin_bit_cast(uint32_t, s);
+  return (sb & 0xffffu) == 0u && s >= 6.103515625e-05f && s <= 16384.f &&
+         __builtin_bit_cast(uint32_t, z) == 0u;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <typename XT, typename CT, int VEC, int RM>
-__global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
-  const UnitInfo u = locate_unit(a.t);
-  if (!u.valid) return;
-  const int lane = threadIdx.x & 63;
-  float s, z;
-  load_scale_zp<CT>(a, u.channel, s, z);
-  const float qmin = a.qmin, qmax = a.qmax;
+// ZP0: the zero-point is +0.0: "+ zp" only turns -0 into +0 and "- zp" is the identity, so their
+// re-roundings are skipped (the values are already representable).
+template <typename CT, int RM, bool ZP0, typename Div>
+__device__ __forceinline__ float fwd_elem(float xf, const Div& div, float s, float z, float qmin,
+                                          float qmax, bool out_int, int mode, float& q_out) {
+  float t = rnd<CT>(div(xf));                  // y = x / scale            int_base.py:69
+  t = ZP0 ? t + 0.f : rnd<CT>(t + z);          // y = y + zero_point       :70
+  t = do_round<CT, RM>(t, mode);               // y = float_to_int_impl(y) :73
+  const float q = clamp_where(t, qmin, qmax);  // y = tensor_clamp_impl(.) :74
+  q_out = q;
+  if (out_int) return q;
+  return ZP0 ? rnd<CT>(q * s) : rnd<CT>(rnd<CT>(q - z) * s);  // (y_int - zero_point) * scale :93-94
+}
 
+template <typename XT, typename CT, int VEC, int RM, bool ZP0, typename Div>
+__device__ __forceinline__ void fwd_unit(const QuantArgs& a, const UnitInfo& u, const Div& div, float s,
+                                         float z, float qmin, float qmax) {
+  const int lane = threadIdx.x & 63;
   const XT* __restrict__ xp = reinterpret_cast<const XT*>(a.x) + u.start;
   CT* __restrict__ yp = reinterpret_cast<CT*>(a.y) + u.start;
   int32_t* __restrict__ cp = a.codes ? a.codes + u.start : nullptr;
   const bool out_int = a.out_int != 0;
+  const int mode = a.round_mode;
 
   const int64_t nvec = u.len / VEC;
   for (int64_t base = 0; base < nvec; base += (int64_t)kWave * kUnroll) {
@@ -101,10 +153,11 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
         vec_t<int32_t, VEC> cv;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          const float xf = to_f<XT>(xv[j].v[k]);
-          const float q = quant_to_int<CT, RM>(xf, s, z, qmin, qmax);
+          float q;
+          const float r =
+              fwd_elem<CT, RM, ZP0>(to_f<XT>(xv[j].v[k]), div, s, z, qmin, qmax, out_int, mode, q);
           cv.v[k] = (int32_t)q;
-          yv.v[k] = from_f<CT>(out_int ? q : dequant<CT>(q, s, z));
+          yv.v[k] = from_f<CT>(r);
         }
         store_vec<CT, VEC>(yp + i * VEC, yv);
         if (cp) store_vec<int32_t, VEC>(cp + i * VEC, cv);
@@ -112,14 +165,30 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
     }
   }
   // ragged end (only the last piece of a single-row tensor can have one)
-  const int64_t tail0 = nvec * VEC;
-  const int64_t i = tail0 + lane;
+  const int64_t i = nvec * VEC + lane;
   if (i < u.len) {
-    const float xf = to_f<XT>(xp[i]);
-    const float q = quant_to_int<CT, RM>(xf, s, z, qmin, qmax);
-    yp[i] = from_f<CT>(out_int ? q : dequant<CT>(q, s, z));
+    float q;
+    const float r = fwd_elem<CT, RM, ZP0>(to_f<XT>(xp[i]), div, s, z, qmin, qmax, out_int, mode, q);
+    yp[i] = from_f<CT>(r);
     if (cp) cp[i] = (int32_t)q;
   }
+}
+
+template <typename XT, typename CT, int VEC, int RM>
+__global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
+  const UnitInfo u = locate_unit(a.t);
+  if (!u.valid) return;
+  float s, z;
+  load_scale_zp<CT>(a, u.channel, s, z);
+  // the reference clamps against min_int/max_int converted to the tensor dtype (max_val.type_as(x))
+  const float qmin = rnd<CT>(a.qmin), qmax = rnd<CT>(a.qmax);
+  if constexpr (elem<CT>::id == BVQ_BF16) {
+    if (bf16_fast_ok(s, z)) {
+      fwd_unit<XT, CT, VEC, RM, true>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
+      return;
+    }
+  }
+  fwd_unit<XT, CT, VEC, RM, false>(a, u, DivExact{s}, s, z, qmin, qmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -130,12 +199,16 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
 //   dx     = (pass ? g*scale : 0) / scale
 //   dscale = sum g*(q - zp)  -  sum dt * ((x/scale)/scale)        (torch: -grad * ((a/b)/b))
 //   dzp    = sum dt  -  sum g*scale
-template <typename CT, int RM, bool NEED_SUMS>
-__device__ __forceinline__ float bwd_elem(float xf, float gf, float s, float z, float qmin, float qmax,
-                                          bool clamp_ste, float& ds_acc, float& dzp_acc) {
-  const float t1 = rnd<CT>(xf / s);
-  const float t2 = rnd<CT>(t1 + z);
-  const float t3 = round_op<CT, RM>(t2);
+// MODE: 0 = dx only, 1 = + dscale, 2 = + dscale and dzp, 3 = + dscale and abs-max tie search.
+enum { kBwdDx = 0, kBwdDs = 1, kBwdDsDzp = 2, kBwdDsTies = 3 };
+
+template <typename CT, int RM, int MODE, bool ZP0, typename Div>
+__device__ __forceinline__ float bwd_elem(float xf, float gf, const Div& div, float s, float z, float qmin,
+                                          float qmax, bool clamp_ste, int mode, float& ds_acc,
+                                          float& dzp_acc) {
+  const float t1 = rnd<CT>(div(xf));
+  const float t2 = ZP0 ? t1 + 0.f : rnd<CT>(t1 + z);
+  const float t3 = do_round<CT, RM>(t2, mode);
   const bool hi = t3 > qmax;
   float t4 = hi ? qmax : t3;
   const bool lo = t4 < qmin;
@@ -143,32 +216,38 @@ __device__ __forceinline__ float bwd_elem(float xf, float gf, float s, float z, 
   const bool pass = clamp_ste || !(hi || lo);
   const float gs = rnd<CT>(gf * s);
   const float dt = pass ? gs : 0.f;
-  const float dxv = rnd<CT>(dt / s);
-  if constexpr (NEED_SUMS) {
-    const float t5 = rnd<CT>(t4 - z);
+  const float dxv = rnd<CT>(div(dt));
+  if constexpr (MODE >= kBwdDs) {
+    const float t5 = ZP0 ? t4 : rnd<CT>(t4 - z);
     const float term1 = rnd<CT>(gf * t5);
-    const float term2 = rnd<CT>(-dt * rnd<CT>(t1 / s));
+    const float term2 = rnd<CT>(-dt * rnd<CT>(div(t1)));
     ds_acc += term1;
     ds_acc += term2;
-    dzp_acc += dt - gs;
   }
+  if constexpr (MODE == kBwdDsDzp) dzp_acc += dt - gs;
   return dxv;
 }
 
-template <typename XT, typename CT, int VEC, int RM, bool NEED_SUMS>
-__global__ __launch_bounds__(kBlock) void fakequant_bwd_kernel(QuantArgs a) {
-  const UnitInfo u = locate_unit(a.t);
-  if (!u.valid) return;
+template <typename XT, typename CT, int VEC, int RM, int MODE, bool ZP0, typename Div>
+__device__ __forceinline__ void bwd_unit(const QuantArgs& a, const UnitInfo& u, const Div& div, float s,
+                                         float z, float qmin, float qmax) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float s, z;
-  load_scale_zp<CT>(a, u.channel, s, z);
-  const float qmin = a.qmin, qmax = a.qmax;
   const bool clamp_ste = a.clamp_ste != 0;
-
+  const int mode = a.round_mode;
   const XT* __restrict__ xp = reinterpret_cast<const XT*>(a.x) + u.start;
   const CT* __restrict__ gp = reinterpret_cast<const CT*>(a.g) + u.start;
   XT* __restrict__ dxp = reinterpret_cast<XT*>(a.y) + u.start;
+
+  // abs-max tie search: position of this unit's first element in the reference's reduction order
+  // of its channel ((outer index) * inner + offset in the row), or the flat index (per-tensor)
+  uint32_t stat_bits = 0;
+  int64_t pos0 = 0;
+  const bool per_channel = a.t.channels > 1;
+  if constexpr (MODE == kBwdDsTies) {
+    stat_bits = abs_bits<XT>(reinterpret_cast<const XT*>(a.tie_stat)[u.channel]);
+    pos0 = per_channel ? (u.row / a.t.channels) * a.inner + u.row_off : u.start;
+  }
 
   float ds_acc = 0.f, dzp_acc = 0.f;
   constexpr int kU = kUnroll / 2 > 0 ? kUnroll / 2 : 1;  // two input streams
@@ -189,31 +268,61 @@ __global__ __launch_bounds__(kBlock) void fakequant_bwd_kernel(QuantArgs a) {
       const int64_t i = base + (int64_t)j * kWave + lane;
       if (i < nvec) {
         vec_t<XT, VEC> dv;
+        bool any_tie = false;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          const float d = bwd_elem<CT, RM, NEED_SUMS>(to_f<XT>(xv[j].v[k]), to_f<CT>(gv[j].v[k]), s, z,
-                                                      qmin, qmax, clamp_ste, ds_acc, dzp_acc);
+          const float d =
+              bwd_elem<CT, RM, MODE, ZP0>(to_f<XT>(xv[j].v[k]), to_f<CT>(gv[j].v[k]), div, s, z, qmin,
+                                          qmax, clamp_ste, mode, ds_acc, dzp_acc);
           dv.v[k] = from_f<XT>(d);
+          if constexpr (MODE == kBwdDsTies) any_tie |= abs_bits<XT>(xv[j].v[k]) == stat_bits;
         }
         store_vec<XT, VEC>(dxp + i * VEC, dv);
+        if constexpr (MODE == kBwdDsTies) {
+          if (any_tie) {  // rare: at most a handful of elements per channel attain the maximum
+            for (int k = 0; k < VEC; ++k)
+              if (abs_bits<XT>(xv[j].v[k]) == stat_bits)
+                record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(pos0 + i * VEC + k));
+          }
+        }
       }
     }
   }
   const int64_t i = nvec * VEC + lane;
   if (i < u.len) {
-    const float d = bwd_elem<CT, RM, NEED_SUMS>(to_f<XT>(xp[i]), to_f<CT>(gp[i]), s, z, qmin, qmax,
-                                                clamp_ste, ds_acc, dzp_acc);
+    const float d = bwd_elem<CT, RM, MODE, ZP0>(to_f<XT>(xp[i]), to_f<CT>(gp[i]), div, s, z, qmin, qmax,
+                                                clamp_ste, mode, ds_acc, dzp_acc);
     dxp[i] = from_f<XT>(d);
-  }
-  if constexpr (NEED_SUMS) {
-    const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-    ds_acc = wave_sum(ds_acc);
-    dzp_acc = wave_sum(dzp_acc);
-    if (lane == 0) {
-      if (a.ds_part) a.ds_part[unit] = ds_acc;
-      if (a.dzp_part) a.dzp_part[unit] = dzp_acc;
+    if constexpr (MODE == kBwdDsTies) {
+      if (abs_bits<XT>(xp[i]) == stat_bits)
+        record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(pos0 + i));
     }
   }
+  if constexpr (MODE >= kBwdDs) {
+    const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    ds_acc = wave_sum(ds_acc);
+    if (lane == 0) a.ds_part[unit] = ds_acc;
+    if constexpr (MODE == kBwdDsDzp) {
+      dzp_acc = wave_sum(dzp_acc);
+      if (lane == 0) a.dzp_part[unit] = dzp_acc;
+    }
+  }
+}
+
+template <typename XT, typename CT, int VEC, int RM, int MODE>
+__global__ __launch_bounds__(kBlock) void fakequant_bwd_kernel(QuantArgs a) {
+  const UnitInfo u = locate_unit(a.t);
+  if (!u.valid) return;
+  float s, z;
+  load_scale_zp<CT>(a, u.channel, s, z);
+  const float qmin = rnd<CT>(a.qmin), qmax = rnd<CT>(a.qmax);
+  if constexpr (elem<CT>::id == BVQ_BF16) {
+    if (bf16_fast_ok(s, z)) {
+      bwd_unit<XT, CT, VEC, RM, MODE, true>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
+      return;
+    }
+  }
+  bwd_unit<XT, CT, VEC, RM, MODE, false>(a, u, DivExact{s}, s, z, qmin, qmax);
 }
 
 // Combine per-unit partial sums of one channel in a fixed order (double accumulation):
@@ -277,9 +386,6 @@ static int validate(const bvq_quant_desc* d) {
     set_error("bad scale/zp dtype");
     return BVQ_ERR_INVALID;
   }
-  if ((d->scale_per_channel || d->zp_per_channel) && d->channels == 1) {
-    // harmless, but keep descriptors canonical
-  }
   return BVQ_OK;
 }
 
@@ -307,85 +413,80 @@ static void fill_args(QuantArgs& a, const bvq_quant_desc* d) {
   a.scalar_cast = d->scalar_mode == BVQ_SCALAR_CAST;
   a.clamp_ste = d->clamp_ste;
   a.out_int = d->out_kind == BVQ_OUT_INT;
+  a.round_mode = d->round_mode;
 }
 
-template <typename XT, typename CT, int VEC>
-static void launch_fwd_rm(const QuantArgs& a, int rm, hipStream_t st) {
-  const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
-  switch (rm) {
-    case BVQ_ROUND:
-      fakequant_fwd_kernel<XT, CT, VEC, BVQ_ROUND><<<grid, block, 0, st>>>(a);
-      break;
-    case BVQ_FLOOR:
-      fakequant_fwd_kernel<XT, CT, VEC, BVQ_FLOOR><<<grid, block, 0, st>>>(a);
-      break;
-    case BVQ_CEIL:
-      fakequant_fwd_kernel<XT, CT, VEC, BVQ_CEIL><<<grid, block, 0, st>>>(a);
-      break;
-    case BVQ_ROUND_TO_ZERO:
-      fakequant_fwd_kernel<XT, CT, VEC, BVQ_ROUND_TO_ZERO><<<grid, block, 0, st>>>(a);
-      break;
-    default:
-      fakequant_fwd_kernel<XT, CT, VEC, BVQ_DPU_ROUND><<<grid, block, 0, st>>>(a);
-      break;
-  }
-}
+// instantiated vector widths: 16 bytes of x per lane, or one element (ragged / misaligned rows)
+static int snap_vec(int vec, int full) { return vec == full ? full : 1; }
 
 template <typename XT, typename CT>
-static void launch_fwd(const QuantArgs& a, int vec, int rm, hipStream_t st) {
+static void launch_fwd(const QuantArgs& a, int vec, hipStream_t st) {
   constexpr int V = elem<XT>::vec;
-  if (vec == V)
-    launch_fwd_rm<XT, CT, V>(a, rm, st);
-  else if (vec == 2 && V > 2)
-    launch_fwd_rm<XT, CT, 2>(a, rm, st);
-  else
-    launch_fwd_rm<XT, CT, 1>(a, rm, st);
-}
-
-template <typename XT, typename CT, int VEC, bool NS>
-static void launch_bwd_rm(const QuantArgs& a, int rm, hipStream_t st) {
   const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
-  switch (rm) {
-    case BVQ_ROUND:
-      fakequant_bwd_kernel<XT, CT, VEC, BVQ_ROUND, NS><<<grid, block, 0, st>>>(a);
-      break;
-    case BVQ_FLOOR:
-      fakequant_bwd_kernel<XT, CT, VEC, BVQ_FLOOR, NS><<<grid, block, 0, st>>>(a);
-      break;
-    case BVQ_CEIL:
-      fakequant_bwd_kernel<XT, CT, VEC, BVQ_CEIL, NS><<<grid, block, 0, st>>>(a);
-      break;
-    case BVQ_ROUND_TO_ZERO:
-      fakequant_bwd_kernel<XT, CT, VEC, BVQ_ROUND_TO_ZERO, NS><<<grid, block, 0, st>>>(a);
-      break;
-    default:
-      fakequant_bwd_kernel<XT, CT, VEC, BVQ_DPU_ROUND, NS><<<grid, block, 0, st>>>(a);
-      break;
-  }
-}
-
-template <typename XT, typename CT>
-static void launch_bwd(const QuantArgs& a, int vec, int rm, bool need_sums, hipStream_t st) {
-  constexpr int V = elem<XT>::vec;
-  if (need_sums) {
-    if (vec == V)
-      launch_bwd_rm<XT, CT, V, true>(a, rm, st);
-    else if (vec == 2 && V > 2)
-      launch_bwd_rm<XT, CT, 2, true>(a, rm, st);
+  const bool rne = a.round_mode == BVQ_ROUND;
+  if (vec == V) {
+    if (rne)
+      fakequant_fwd_kernel<XT, CT, V, BVQ_ROUND><<<grid, block, 0, st>>>(a);
     else
-      launch_bwd_rm<XT, CT, 1, true>(a, rm, st);
+      fakequant_fwd_kernel<XT, CT, V, kAnyRM><<<grid, block, 0, st>>>(a);
   } else {
-    if (vec == V)
-      launch_bwd_rm<XT, CT, V, false>(a, rm, st);
-    else if (vec == 2 && V > 2)
-      launch_bwd_rm<XT, CT, 2, false>(a, rm, st);
+    if (rne)
+      fakequant_fwd_kernel<XT, CT, 1, BVQ_ROUND><<<grid, block, 0, st>>>(a);
     else
-      launch_bwd_rm<XT, CT, 1, false>(a, rm, st);
+      fakequant_fwd_kernel<XT, CT, 1, kAnyRM><<<grid, block, 0, st>>>(a);
   }
 }
 
-// vec widths actually instantiated: full (16 B of x), 2 and 1
-static int snap_vec(int vec, int full) { return vec == full ? full : (vec >= 2 && full > 2 ? 2 : 1); }
+template <typename XT, typename CT, int MODE>
+static void launch_bwd_mode(const QuantArgs& a, int vec, hipStream_t st) {
+  constexpr int V = elem<XT>::vec;
+  const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
+  const bool rne = a.round_mode == BVQ_ROUND;
+  if (vec == V) {
+    if (rne)
+      fakequant_bwd_kernel<XT, CT, V, BVQ_ROUND, MODE><<<grid, block, 0, st>>>(a);
+    else
+      fakequant_bwd_kernel<XT, CT, V, kAnyRM, MODE><<<grid, block, 0, st>>>(a);
+  } else {
+    if (rne)
+      fakequant_bwd_kernel<XT, CT, 1, BVQ_ROUND, MODE><<<grid, block, 0, st>>>(a);
+    else
+      fakequant_bwd_kernel<XT, CT, 1, kAnyRM, MODE><<<grid, block, 0, st>>>(a);
+  }
+}
+
+template <typename XT, typename CT>
+static void launch_bwd(const QuantArgs& a, int vec, int mode, hipStream_t st) {
+  switch (mode) {
+    case kBwdDx:
+      launch_bwd_mode<XT, CT, kBwdDx>(a, vec, st);
+      break;
+    case kBwdDs:
+      launch_bwd_mode<XT, CT, kBwdDs>(a, vec, st);
+      break;
+    case kBwdDsDzp:
+      launch_bwd_mode<XT, CT, kBwdDsDzp>(a, vec, st);
+      break;
+    default:
+      launch_bwd_mode<XT, CT, kBwdDsTies>(a, vec, st);
+      break;
+  }
+}
+
+#define BVQ_DISPATCH_PAIR(d, CALL)                                      \
+  do {                                                                  \
+    if ((d)->x_dtype == BVQ_F32) {                                      \
+      CALL(float, float);                                               \
+    } else if ((d)->x_dtype == BVQ_BF16 && (d)->ct_dtype == BVQ_BF16) { \
+      CALL(bf16_t, bf16_t);                                             \
+    } else if ((d)->x_dtype == BVQ_BF16) {                              \
+      CALL(bf16_t, float);                                              \
+    } else if ((d)->x_dtype == BVQ_F16 && (d)->ct_dtype == BVQ_F16) {   \
+      CALL(f16_t, f16_t);                                               \
+    } else {                                                            \
+      CALL(f16_t, float);                                               \
+    }                                                                   \
+  } while (0)
 
 }  // namespace bvq
 
@@ -417,16 +518,9 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
   a.codes = codes;
   fill_args(a, d);
   hipStream_t st = (hipStream_t)stream;
-  if (d->x_dtype == BVQ_F32)
-    launch_fwd<float, float>(a, vec, d->round_mode, st);
-  else if (d->x_dtype == BVQ_BF16 && d->ct_dtype == BVQ_BF16)
-    launch_fwd<bf16_t, bf16_t>(a, vec, d->round_mode, st);
-  else if (d->x_dtype == BVQ_BF16)
-    launch_fwd<bf16_t, float>(a, vec, d->round_mode, st);
-  else if (d->x_dtype == BVQ_F16 && d->ct_dtype == BVQ_F16)
-    launch_fwd<f16_t, f16_t>(a, vec, d->round_mode, st);
-  else
-    launch_fwd<f16_t, float>(a, vec, d->round_mode, st);
+#define BVQ_CALL(XT, CT) launch_fwd<XT, CT>(a, vec, st)
+  BVQ_DISPATCH_PAIR(d, BVQ_CALL);
+#undef BVQ_CALL
   return check_launch("bvq_fakequant_fwd");
 }
 
@@ -434,14 +528,11 @@ static int64_t bwd_units(const bvq_quant_desc* d) {
   int64_t rows, row_len;
   int32_t channels;
   rows_of(d, rows, row_len, channels);
-  // upper bound over every vector width the launcher may pick
-  int64_t worst = 0;
+  // upper bound over the vector widths the launcher may pick
   const int full = 16 / dtype_size(d->x_dtype);
-  for (int v = 1; v <= full; v <<= 1) {
-    Tiling t = make_tiling(rows, row_len, channels, v);
-    if (t.units > worst) worst = t.units;
-  }
-  return worst;
+  const int64_t a = make_tiling(rows, row_len, channels, full).units;
+  const int64_t b = make_tiling(rows, row_len, channels, 1).units;
+  return a > b ? a : b;
 }
 
 extern "C" int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* d) {
@@ -451,8 +542,8 @@ extern "C" int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* d) {
 
 extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const void* x,
                                  const void* scale, const void* zp, void* dx, float* dscale,
-                                 float* dzp, void* workspace, int64_t workspace_bytes,
-                                 bvq_stream_t stream) {
+                                 float* dzp, const void* tie_stat, int64_t* tie_info, void* workspace,
+                                 int64_t workspace_bytes, bvq_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
   const int64_t n = d->outer * d->channels * d->inner;
@@ -461,6 +552,20 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   int32_t channels;
   rows_of(d, rows, row_len, channels);
   const bool need_sums = dscale != nullptr || dzp != nullptr;
+  if ((tie_stat != nullptr) != (tie_info != nullptr)) {
+    set_error("bvq_fakequant_bwd: tie_stat and tie_info go together");
+    return BVQ_ERR_INVALID;
+  }
+  if (tie_stat && (!dscale || dzp)) {
+    set_error("bvq_fakequant_bwd: the tie search rides on the dscale variant (dscale set, dzp null)");
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  if (tie_stat && channels != d->channels) {
+    set_error("bvq_fakequant_bwd: tie search needs the statistic's layout (per-channel scale iff "
+              "channels > 1)");
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  if (tie_info) launch_tie_init(reinterpret_cast<unsigned long long*>(tie_info), channels, st);
   if (n == 0) {
     if (dscale) (void)hipMemsetAsync(dscale, 0, sizeof(float) * channels, st);
     if (dzp) (void)hipMemsetAsync(dzp, 0, sizeof(float) * channels, st);
@@ -491,17 +596,14 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   a.scale = scale;
   a.zp = zp;
   a.y = dx;
+  a.tie_stat = tie_stat;
+  a.tie_info = reinterpret_cast<unsigned long long*>(tie_info);
+  a.inner = d->inner;
   fill_args(a, d);
-  if (d->x_dtype == BVQ_F32)
-    launch_bwd<float, float>(a, vec, d->round_mode, need_sums, st);
-  else if (d->x_dtype == BVQ_BF16 && d->ct_dtype == BVQ_BF16)
-    launch_bwd<bf16_t, bf16_t>(a, vec, d->round_mode, need_sums, st);
-  else if (d->x_dtype == BVQ_BF16)
-    launch_bwd<bf16_t, float>(a, vec, d->round_mode, need_sums, st);
-  else if (d->x_dtype == BVQ_F16 && d->ct_dtype == BVQ_F16)
-    launch_bwd<f16_t, f16_t>(a, vec, d->round_mode, need_sums, st);
-  else
-    launch_bwd<f16_t, float>(a, vec, d->round_mode, need_sums, st);
+  const int mode = tie_stat ? kBwdDsTies : (dzp ? kBwdDsDzp : (dscale ? kBwdDs : kBwdDx));
+#define BVQ_CALL(XT, CT) launch_bwd<XT, CT>(a, vec, mode, st)
+  BVQ_DISPATCH_PAIR(d, BVQ_CALL);
+#undef BVQ_CALL
   rc = check_launch("bvq_fakequant_bwd");
   if (rc) return rc;
   if (need_sums) {

@@ -39,27 +39,30 @@ __device__ __forceinline__ float round_op(float t) {
   }
 }
 
+// runtime-selected rounding mode (the rarely used variants share one kernel instantiation)
+constexpr int kAnyRM = -1;
+template <typename CT>
+__device__ __forceinline__ float round_any(float t, int mode) {
+  switch (mode) {
+    case BVQ_ROUND:
+      return round_op<CT, BVQ_ROUND>(t);
+    case BVQ_FLOOR:
+      return round_op<CT, BVQ_FLOOR>(t);
+    case BVQ_CEIL:
+      return round_op<CT, BVQ_CEIL>(t);
+    case BVQ_ROUND_TO_ZERO:
+      return round_op<CT, BVQ_ROUND_TO_ZERO>(t);
+    default:
+      return round_op<CT, BVQ_DPU_ROUND>(t);
+  }
+}
+
 // tensor_clamp: where(x > max, max, x) then where(out < min, min, out)  (B/function/ops.py:98-100)
 // NaN fails both comparisons and passes through, as in the reference.
 __device__ __forceinline__ float clamp_where(float t, float qmin, float qmax) {
   t = t > qmax ? qmax : t;
   t = t < qmin ? qmin : t;
   return t;
-}
-
-// IntQuant.to_int (B/core/quant/int_base.py:63-76)
-template <typename CT, int RM>
-__device__ __forceinline__ float quant_to_int(float xf, float s, float z, float qmin, float qmax) {
-  float t = rnd<CT>(xf / s);
-  t = rnd<CT>(t + z);
-  t = round_op<CT, RM>(t);
-  return clamp_where(t, qmin, qmax);
-}
-
-// IntQuant.forward tail (B/core/quant/int_base.py:93-95)
-template <typename CT>
-__device__ __forceinline__ float dequant(float q, float s, float z) {
-  return rnd<CT>(rnd<CT>(q - z) * s);
 }
 
 }  // namespace bvq

@@ -9,6 +9,7 @@
 // of (bits & ~sign), and every NaN pattern is larger than +inf, so an unsigned max IS
 // torch.max(torch.abs(x)) including its NaN propagation.  The result is exact (a max never rounds).
 #include "bvq_common.h"
+#include "bvq_ties.h"
 
 namespace bvq {
 
@@ -34,23 +35,6 @@ __device__ __forceinline__ bool locate(const Tiling& t, int64_t& unit, int64_t& 
   len = rest < t.piece_len ? rest : t.piece_len;
   channel = (int32_t)(row % t.channels);
   return true;
-}
-
-// |v| as a float32 bit pattern
-template <typename T>
-__device__ __forceinline__ uint32_t abs_bits(T v);
-template <>
-__device__ __forceinline__ uint32_t abs_bits<float>(float v) {
-  return __builtin_bit_cast(uint32_t, v) & 0x7fffffffu;
-}
-template <>
-__device__ __forceinline__ uint32_t abs_bits<bf16_t>(bf16_t v) {
-  return ((uint32_t)(__builtin_bit_cast(uint16_t, v) & 0x7fffu)) << 16;
-}
-template <>
-__device__ __forceinline__ uint32_t abs_bits<f16_t>(f16_t v) {
-  // compare in the 16-bit pattern domain (order preserving); widened to f32 by the finisher
-  return (uint32_t)(__builtin_bit_cast(uint16_t, v) & 0x7fffu);
 }
 
 template <typename T, int VEC>
@@ -213,12 +197,6 @@ __global__ __launch_bounds__(kBlock) void stat_finish_kernel(const uint32_t* __r
 // gradient there.  MATCH_ABS: |x| == stat, deposit scaled by sgn(x) (torch.abs backward);
 // MATCH_VALUE: x == stat (torch.max / torch.min of x itself).
 // ------------------------------------------------------------------------------------------------
-// tie_info layout (int64 words):
-//   channels > 1 : first[c]  = smallest (outer*inner + i) position matching stat[c]  (init: max)
-//   channels == 1: [0] = number of ties (also the list cursor), [1] = unused,
-//                  [2 .. 2+kTieCap) = flat element indices of the first kTieCap ties found
-constexpr int kTieCap = 1024;
-
 // torch.abs backward uses sgn(x): 0 at 0
 __device__ __forceinline__ float sgn_f(float v) { return (float)(0.f < v) - (float)(v < 0.f); }
 
@@ -267,13 +245,7 @@ __global__ __launch_bounds__(kBlock) void tie_scan_kernel(Tiling t, const void* 
       for (int k = 0; k < VEC; ++k) {
         zv.v[k] = zero_like<T, MATCH>(xv.v[k]);
         if (is_tie<T, MATCH>(xv.v[k], sv)) {
-          const unsigned long long pos = (unsigned long long)(pos0 + e0 + k);
-          if (per_channel) {
-            atomicMin(&info[channel], pos);
-          } else {
-            const unsigned long long slot = atomicAdd(&info[0], 1ull);
-            if (slot < (unsigned long long)kTieCap) info[2 + slot] = pos;
-          }
+          record_tie(info, per_channel, channel, (unsigned long long)(pos0 + e0 + k));
         }
       }
       if (WRITE_ZERO) store_vec<T, VEC>(dp + e0, zv);
@@ -282,13 +254,7 @@ __global__ __launch_bounds__(kBlock) void tie_scan_kernel(Tiling t, const void* 
       for (int64_t e = nvec * VEC; e < len; ++e) {
         if (WRITE_ZERO) dp[e] = zero_like<T, MATCH>(xp[e]);
         if (is_tie<T, MATCH>(xp[e], sv)) {
-          const unsigned long long pos = (unsigned long long)(pos0 + e);
-          if (per_channel) {
-            atomicMin(&info[channel], pos);
-          } else {
-            const unsigned long long slot = atomicAdd(&info[0], 1ull);
-            if (slot < (unsigned long long)kTieCap) info[2 + slot] = pos;
-          }
+          record_tie(info, per_channel, channel, (unsigned long long)(pos0 + e));
         }
       }
     }
@@ -302,6 +268,10 @@ __global__ void tie_init_kernel(unsigned long long* info, int32_t channels) {
   } else {
     if (i < 2) info[i] = 0ull;
   }
+}
+
+void launch_tie_init(unsigned long long* info, int64_t channels, hipStream_t st) {
+  tie_init_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, st>>>(info, (int32_t)channels);
 }
 
 template <typename T, int MATCH>
@@ -334,15 +304,16 @@ __global__ void tie_apply_first_kernel(const void* x, const void* gstat, const u
 // channels == 1, ties fit the list: each tie receives (gstat / count)
 template <typename T, int MATCH>
 __global__ void tie_apply_list_kernel(const void* x, const void* gstat, const unsigned long long* info,
-                                      void* dx, int mode_add) {
-  const unsigned long long cnt = info[0];
-  if (cnt == 0 || cnt > (unsigned long long)kTieCap) return;
+                                      const unsigned long long* total, void* dx, int mode_add) {
+  const unsigned long long local = info[0];
+  if (local == 0 || local > (unsigned long long)kTieCap) return;
+  const unsigned long long cnt = total ? total[0] : local;  // ties over all shards of the tensor
   const T* xp = reinterpret_cast<const T*>(x);
   T* dp = reinterpret_cast<T*>(dx);
   // grad / mask.sum(): the count is an integer tensor, the quotient has the gradient's dtype
   // (the integer count is converted to the gradient's dtype first, as torch's type promotion does)
   const float share = rnd<T>(to_f<T>(reinterpret_cast<const T*>(gstat)[0]) / rnd<T>((float)cnt));
-  for (unsigned long long k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt;
+  for (unsigned long long k = blockIdx.x * blockDim.x + threadIdx.x; k < local;
        k += (unsigned long long)gridDim.x * blockDim.x) {
     const int64_t flat = (int64_t)info[2 + k];
     const float term = deposit<T, MATCH>(share, xp[flat]);
@@ -354,10 +325,12 @@ __global__ void tie_apply_list_kernel(const void* x, const void* gstat, const un
 template <typename T, int MATCH>
 __global__ __launch_bounds__(kBlock) void tie_apply_full_kernel(const void* x, const void* stat,
                                                                 const void* gstat,
-                                                                const unsigned long long* info, void* dx,
-                                                                int64_t n, int mode_add) {
-  const unsigned long long cnt = info[0];
-  if (cnt <= (unsigned long long)kTieCap) return;
+                                                                const unsigned long long* info,
+                                                                const unsigned long long* total,
+                                                                void* dx, int64_t n, int mode_add) {
+  const unsigned long long local = info[0];
+  if (local <= (unsigned long long)kTieCap) return;
+  const unsigned long long cnt = total ? total[0] : local;
   const T* xp = reinterpret_cast<const T*>(x);
   T* dp = reinterpret_cast<T*>(dx);
   const T sv = reinterpret_cast<const T*>(stat)[0];
@@ -438,25 +411,31 @@ static void launch_tie_scan_v(const Tiling& t, int vec, const void* x, const voi
 }
 
 template <typename T, int MATCH>
-static void run_stat_bwd(const Tiling& t, int vec, const void* x, const void* stat, const void* gstat,
-                         unsigned long long* info, void* dx, int64_t outer, int64_t channels,
-                         int64_t inner, int mode_add, hipStream_t st) {
-  if (mode_add)
-    launch_tie_scan_v<T, MATCH, false>(t, vec, x, stat, info, dx, inner, st);
-  else
+static void run_tie_scan(const Tiling& t, int vec, const void* x, const void* stat,
+                         unsigned long long* info, void* dx, int64_t inner, int write_zeros,
+                         hipStream_t st) {
+  if (write_zeros)
     launch_tie_scan_v<T, MATCH, true>(t, vec, x, stat, info, dx, inner, st);
+  else
+    launch_tie_scan_v<T, MATCH, false>(t, vec, x, stat, info, dx, inner, st);
+}
+
+template <typename T, int MATCH>
+static void run_tie_apply(const void* x, const void* stat, const void* gstat,
+                          const unsigned long long* info, const unsigned long long* total, void* dx,
+                          int64_t outer, int64_t channels, int64_t inner, int mode_add, hipStream_t st) {
   if (channels > 1) {
     const unsigned nb = (unsigned)((channels + 255) / 256);
     tie_apply_first_kernel<T, MATCH><<<dim3(nb), dim3(256), 0, st>>>(x, gstat, info, dx, outer,
                                                                      (int32_t)channels, inner, mode_add);
   } else {
-    tie_apply_list_kernel<T, MATCH><<<dim3(4), dim3(256), 0, st>>>(x, gstat, info, dx, mode_add);
+    tie_apply_list_kernel<T, MATCH><<<dim3(4), dim3(256), 0, st>>>(x, gstat, info, total, dx, mode_add);
     const int64_t n = outer * inner;
     int64_t nb = (n + kBlock - 1) / kBlock;
     if (nb > 2048) nb = 2048;
     // exits immediately unless the tie list overflowed
     tie_apply_full_kernel<T, MATCH><<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(x, stat, gstat, info,
-                                                                                 dx, n, mode_add);
+                                                                                 total, dx, n, mode_add);
   }
 }
 
@@ -527,52 +506,102 @@ extern "C" int bvq_stats(int kind, int dtype, const void* x, int64_t outer, int6
   return check_launch("bvq_stats/finish");
 }
 
-extern "C" int bvq_stat_bwd(int match, int dtype, const void* x, const void* stat, const void* gstat,
-                            void* dx, int64_t outer, int64_t channels, int64_t inner, int mode_add,
-                            void* workspace, int64_t workspace_bytes, bvq_stream_t stream) {
+#define BVQ_DISPATCH_T_MATCH(dtype, match, FN, ...)              \
+  do {                                                             \
+    if ((dtype) == BVQ_F32) {                                      \
+      if ((match) == BVQ_MATCH_ABS)                                \
+        FN<float, BVQ_MATCH_ABS>(__VA_ARGS__);                     \
+      else                                                         \
+        FN<float, BVQ_MATCH_VALUE>(__VA_ARGS__);                   \
+    } else if ((dtype) == BVQ_BF16) {                              \
+      if ((match) == BVQ_MATCH_ABS)                                \
+        FN<bf16_t, BVQ_MATCH_ABS>(__VA_ARGS__);                    \
+      else                                                         \
+        FN<bf16_t, BVQ_MATCH_VALUE>(__VA_ARGS__);                  \
+    } else {                                                       \
+      if ((match) == BVQ_MATCH_ABS)                                \
+        FN<f16_t, BVQ_MATCH_ABS>(__VA_ARGS__);                     \
+      else                                                         \
+        FN<f16_t, BVQ_MATCH_VALUE>(__VA_ARGS__);                   \
+    }                                                              \
+  } while (0)
+
+static int check_stat_args(const char* fn, int match, int dtype, int64_t outer, int64_t channels,
+                           int64_t inner) {
   if (bad_dtype(dtype) || outer < 0 || channels < 1 || inner < 0 ||
       (match != BVQ_MATCH_ABS && match != BVQ_MATCH_VALUE)) {
-    set_error("bvq_stat_bwd: bad argument");
+    set_error("%s: bad argument", fn);
     return BVQ_ERR_INVALID;
   }
-  const int64_t n = outer * channels * inner;
-  if (n == 0) return BVQ_OK;
-  if (!x || !stat || !gstat || !dx || !workspace) {
-    set_error("bvq_stat_bwd: null pointer");
+  return BVQ_OK;
+}
+
+extern "C" int64_t bvq_tie_info_bytes(int64_t channels) {
+  if (channels < 1) return -1;
+  return tie_info_words(channels) * (int64_t)sizeof(int64_t);
+}
+
+extern "C" int bvq_stat_tie_scan(int match, int dtype, const void* x, const void* stat, int64_t outer,
+                                 int64_t channels, int64_t inner, void* dx_zero_fill, int64_t* tie_info,
+                                 bvq_stream_t stream) {
+  int rc = check_stat_args("bvq_stat_tie_scan", match, dtype, outer, channels, inner);
+  if (rc) return rc;
+  if (!tie_info) {
+    set_error("bvq_stat_tie_scan: null tie_info");
     return BVQ_ERR_INVALID;
-  }
-  const int64_t tie_words = channels > 1 ? channels : 2 + kTieCap;
-  if (workspace_bytes < tie_words * (int64_t)sizeof(int64_t)) {
-    set_error("bvq_stat_bwd: workspace too small");
-    return BVQ_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  unsigned long long* info = reinterpret_cast<unsigned long long*>(workspace);
+  unsigned long long* info = reinterpret_cast<unsigned long long*>(tie_info);
+  launch_tie_init(info, channels, st);
+  if (outer * channels * inner == 0) return check_launch("bvq_stat_tie_scan");
+  if (!x || !stat) {
+    set_error("bvq_stat_tie_scan: null pointer");
+    return BVQ_ERR_INVALID;
+  }
   int vec;
-  const void* ptrs[2] = {x, dx};
   Tiling t = stat_tiling(dtype, x, outer, channels, inner, vec);
-  if (reinterpret_cast<uintptr_t>(dx) % 16 != 0 && vec > 1) {
+  if (dx_zero_fill && reinterpret_cast<uintptr_t>(dx_zero_fill) % 16 != 0 && vec > 1) {
     vec = 1;
     t = make_tiling(t.rows, t.row_len, t.channels, 1);
   }
-  (void)ptrs;
-  tie_init_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, st>>>(info,
-                                                                                  (int32_t)channels);
-#define BVQ_RUN(T)                                                                                       \
-  do {                                                                                                   \
-    if (match == BVQ_MATCH_ABS)                                                                          \
-      run_stat_bwd<T, BVQ_MATCH_ABS>(t, vec, x, stat, gstat, info, dx, outer, channels, inner, mode_add, \
-                                     st);                                                                \
-    else                                                                                                 \
-      run_stat_bwd<T, BVQ_MATCH_VALUE>(t, vec, x, stat, gstat, info, dx, outer, channels, inner,         \
-                                       mode_add, st);                                                    \
-  } while (0)
-  if (dtype == BVQ_F32)
-    BVQ_RUN(float);
-  else if (dtype == BVQ_BF16)
-    BVQ_RUN(bf16_t);
-  else
-    BVQ_RUN(f16_t);
-#undef BVQ_RUN
-  return check_launch("bvq_stat_bwd");
+  BVQ_DISPATCH_T_MATCH(dtype, match, run_tie_scan, t, vec, x, stat, info, dx_zero_fill, inner,
+                       dx_zero_fill != nullptr, st);
+  return check_launch("bvq_stat_tie_scan");
+}
+
+extern "C" int bvq_stat_tie_apply(int match, int dtype, const void* x, const void* stat, const void* gstat,
+                                  const int64_t* tie_info, const int64_t* total_ties, void* dx,
+                                  int64_t outer, int64_t channels, int64_t inner, int mode_add,
+                                  bvq_stream_t stream) {
+  int rc = check_stat_args("bvq_stat_tie_apply", match, dtype, outer, channels, inner);
+  if (rc) return rc;
+  if (outer * channels * inner == 0) return BVQ_OK;
+  if (!x || !stat || !gstat || !tie_info || !dx) {
+    set_error("bvq_stat_tie_apply: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  BVQ_DISPATCH_T_MATCH(dtype, match, run_tie_apply, x, stat, gstat,
+                       reinterpret_cast<const unsigned long long*>(tie_info),
+                       reinterpret_cast<const unsigned long long*>(total_ties), dx, outer, channels, inner,
+                       mode_add, st);
+  return check_launch("bvq_stat_tie_apply");
+}
+
+extern "C" int bvq_stat_bwd(int match, int dtype, const void* x, const void* stat, const void* gstat,
+                            void* dx, int64_t outer, int64_t channels, int64_t inner, int mode_add,
+                            void* workspace, int64_t workspace_bytes, bvq_stream_t stream) {
+  int rc = check_stat_args("bvq_stat_bwd", match, dtype, outer, channels, inner);
+  if (rc) return rc;
+  if (outer * channels * inner == 0) return BVQ_OK;
+  if (!workspace || workspace_bytes < bvq_tie_info_bytes(channels)) {
+    set_error("bvq_stat_bwd: workspace too small");
+    return BVQ_ERR_WORKSPACE;
+  }
+  int64_t* info = reinterpret_cast<int64_t*>(workspace);
+  rc = bvq_stat_tie_scan(match, dtype, x, stat, outer, channels, inner, mode_add ? nullptr : dx, info,
+                         stream);
+  if (rc) return rc;
+  return bvq_stat_tie_apply(match, dtype, x, stat, gstat, info, nullptr, dx, outer, channels, inner,
+                            mode_add, stream);
 }

@@ -1,0 +1,88 @@
+"""Batch-sharded fake-quantization: one process per GPU, the activation split along dim 0.
+
+The quantize/dequantize math is independent per element; only the scale statistic couples the
+shards.  So the path shards with NO data-path collective except
+
+  forward   one all-reduce(MAX) of the per-channel (or whole-tensor) abs-max     <= 4 KB
+  backward  one all-gather of [scale-gradient partial sums | tie ownership]       <= 8 KB x ranks
+
+over RCCL/xGMI (backend "nccl" on ROCm; "gloo" works for CPU tensors in tests).  Both are
+latency-bound messages; they sit between the statistic kernel and the quantize kernel (resp. between
+the backward kernel and the tiny deposit kernel), so no extra pass over the tensor is made.
+
+Semantics: the result equals the single-device result on the concatenated batch (a max is exact and
+associative, so y is bit-identical); the reference itself has no cross-device reduction
+(nn.DataParallel replicas use local statistics).  The statistic's gradient is deposited
+where the single-device run would put it: on the first arg-max in batch order, i.e. on the lowest
+rank that holds one (per-channel), or evenly over all ties of all shards (whole tensor).  The
+scale-gradient sums are combined in rank order on every rank: bit-identical across ranks and
+run-to-run.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+_NO_OWNER = float(1 << 30)
+
+
+def shard_over_batch(quantizer, group=None):
+    """Mark a RescalingIntQuant as operating on one batch shard of a tensor spread over `group`
+    (default: the world group).  Only the fused stats-scaled activation graph uses it."""
+    if not dist.is_initialized():
+        raise RuntimeError('shard_over_batch: torch.distributed is not initialised')
+    quantizer.bvq_shard_group = group if group is not None else dist.group.WORLD
+    return quantizer
+
+
+def world_of(group) -> Tuple[int, int]:
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def sync_stat_max(stat_f32: Tensor, group) -> Tensor:
+    """in-place all-reduce(MAX) of a float32 statistic; returns it"""
+    if dist.get_world_size(group) > 1:
+        dist.all_reduce(stat_f32, op=dist.ReduceOp.MAX, group=group)
+    return stat_f32
+
+
+def sync_backward(ds_local: Tensor, tie_info: Tensor, channels: int, group
+                  ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+    """Combine the shards' backward bookkeeping with ONE all-gather.
+
+    ds_local : float32 [channels]   this shard's partial sums of the scale gradient
+    tie_info : int64 buffer written by the backward kernel (include/bvq.h, bvq_stat_tie_scan):
+               channels > 1: word c = first local position attaining the statistic, or -1
+               channels == 1: word 0 = number of local ties
+    returns (ds_total float32 [channels], tie_info with non-owned channels disabled,
+             total_ties int64 [1] or None)
+    """
+    rank, world = world_of(group)
+    per_channel = channels > 1
+    if per_channel:
+        has = tie_info[:channels] >= 0
+        key = torch.where(has, torch.full_like(ds_local, float(rank), dtype=torch.float64),
+                          torch.full_like(ds_local, _NO_OWNER, dtype=torch.float64))
+    else:
+        key = tie_info[:1].to(torch.float64)
+    mine = torch.stack([ds_local.to(torch.float64), key])  # [2, channels]
+    if world > 1:
+        flat = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(flat, mine.reshape(-1).contiguous(), group=group)
+        allr = flat.reshape((world,) + tuple(mine.shape))
+    else:
+        allr = mine.unsqueeze(0)
+    # fixed (rank) order: every rank computes the same bits
+    ds_total = allr[0, 0].clone()
+    for r in range(1, world):
+        ds_total += allr[r, 0]
+    ds_total = ds_total.to(torch.float32)
+    if per_channel:
+        owner = allr[:, 1].min(dim=0).values
+        out = tie_info.clone()
+        out[:channels] = torch.where(owner == float(rank), tie_info[:channels],
+                                     torch.full_like(tie_info[:channels], -1))
+        return ds_total, out, None
+    total = allr[:, 1].sum(dim=0).to(torch.int64).reshape(1)
+    return ds_total, tie_info, total

@@ -181,6 +181,25 @@ int bvq_stat_bwd(int match, int dtype, const void* x, const void* stat, const vo
                  int64_t outer, int64_t channels, int64_t inner, int mode_add, void* workspace,
                  int64_t workspace_bytes, bvq_stream_t stream);
 
+/* The two halves of bvq_stat_bwd, for callers that put work between them (batch-sharded tensors:
+ * the ranks agree on which shard owns each channel's first maximum before anything is deposited).
+ * tie_info: device buffer of bvq_tie_info_bytes(channels) bytes, int64 words:
+ *   channels > 1 : word c = smallest (outer*inner + i) position attaining stat[c], or -1 if none;
+ *                  setting a word to -1 suppresses that channel's deposit;
+ *   channels == 1: word 0 = number of ties found, words 2.. = flat indices of (up to 1024 of) them.
+ * bvq_stat_tie_scan: one streaming read of x; if dx_zero_fill is non-null it is also written with
+ *   the zeros non-attaining elements receive (signed by sgn(x) for MATCH_ABS).
+ * bvq_stat_tie_apply: deposits gstat at the recorded positions.  total_ties (nullable, device, one
+ *   int64) replaces the local tie count when the ties of a whole-tensor maximum are spread over
+ *   several shards. */
+int64_t bvq_tie_info_bytes(int64_t channels);
+int bvq_stat_tie_scan(int match, int dtype, const void* x, const void* stat, int64_t outer,
+                      int64_t channels, int64_t inner, void* dx_zero_fill, int64_t* tie_info,
+                      bvq_stream_t stream);
+int bvq_stat_tie_apply(int match, int dtype, const void* x, const void* stat, const void* gstat,
+                       const int64_t* tie_info, const int64_t* total_ties, void* dx, int64_t outer,
+                       int64_t channels, int64_t inner, int mode_add, bvq_stream_t stream);
+
 /* ---- fused affine quantize / dequantize (seam 2: IntQuant) ---------------------------------- */
 
 /* Forward: one read of x, one write of y.
@@ -202,10 +221,14 @@ int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* desc);
  *   dzp[c]    = sum dt - sum g*scale                                      (float32, nullable)
  * dscale / dzp have `channels` elements when scale OR zero-point is per-channel, else one.
  * One read of g, one read of x, one write of dx; the per-channel sums ride on the same reads and
- * are combined in a fixed order (bit-reproducible run to run). */
+ * are combined in a fixed order (bit-reproducible run to run).
+ * tie_stat / tie_info (both null or both set; requires dscale set and dzp null): while streaming x
+ * the kernel also records which elements attain the abs-max statistic tie_stat (dtype of x,
+ * `channels` elements) into tie_info (see bvq_stat_tie_scan), so that the statistic's gradient can
+ * be deposited with bvq_stat_tie_apply without another pass over x. */
 int bvq_fakequant_bwd(const bvq_quant_desc* desc, const void* g, const void* x, const void* scale,
-                      const void* zp, void* dx, float* dscale, float* dzp, void* workspace,
-                      int64_t workspace_bytes, bvq_stream_t stream);
+                      const void* zp, void* dx, float* dscale, float* dzp, const void* tie_stat,
+                      int64_t* tie_info, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
 
 #ifdef __cplusplus
 }
