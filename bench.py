@@ -119,7 +119,7 @@ def cpu_baseline(shape, dtype, per_channel, budget_s=12.0):
         O.step_stats_scaled(d, xn, gn, 1e-10, 128.0)
         iters += 1
         el = time.perf_counter() - t0
-        if el > budget_s or iters >= 50:
+        if el > budget_s or iters >= 400:
             break
     elems = n * c * h * w
     return {
@@ -141,6 +141,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    shape, dtype, per_channel, descr = WORKLOADS[args.workload]
+    # The CPU baseline runs FIRST, before this process touches the GPU: it may have to (re)build the
+    # oracle with `make`, and a GPU-initialised process must not spawn other programs on the box.
+    baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        baseline = cpu_baseline(shape, dtype, per_channel)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, args.gpus))
@@ -156,7 +162,6 @@ def main():
         group = dist.group.WORLD
 
     from brevitas_amd import _native as nat
-    shape, dtype, per_channel, descr = WORKLOADS[args.workload]
     torch.manual_seed(123456 + rank)
     x = torch.randn(shape, device=device, dtype=dtype).requires_grad_(True)
     g = torch.randn(shape, device=device, dtype=dtype)
@@ -224,8 +229,8 @@ def main():
                          'traffic': traffic, 'algorithmic_bytes_per_launch': bwd_bytes,
                          'avg_launch_ms': round(bwd_ms, 4) if bwd_ms else None},
         }
-        if not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(shape, dtype, per_channel)
+        if baseline is not None:
+            out['cpu_baseline'] = baseline
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -12,7 +12,8 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libbvq.so')
+# BREVITAS_AMD_LIB: developer override to load an experimental build of the same ABI (tools/microbench.py)
+LIB_PATH = os.environ.get('BREVITAS_AMD_LIB') or os.path.join(_PKG, 'libbvq.so')
 
 F32, BF16, F16 = 0, 1, 2
 ROUND, FLOOR, CEIL, ROUND_TO_ZERO, DPU_ROUND = range(5)
@@ -29,7 +30,7 @@ _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 EXPORTS = (
     'bvq_abi_version', 'bvq_last_error', 'bvq_unary', 'bvq_scalar_clamp', 'bvq_tensor_clamp',
     'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
-    'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
+    'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
 
 
 class QuantDesc(ctypes.Structure):
@@ -47,12 +48,13 @@ class BvqError(RuntimeError):
     pass
 
 
-def _load():
-    if not os.path.exists(LIB_PATH):
+def _load(path=None):
+    path = path or LIB_PATH
+    if not os.path.exists(path):
         raise ImportError(
             'brevitas_amd: %s is missing. Build it with `python -m brevitas_amd.csrc.build` '
-            '(needs hipcc, gfx950). There is no fallback backend.' % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            '(needs hipcc, gfx950). There is no fallback backend.' % path)
+    lib = ctypes.CDLL(path)
     vp, i64, i32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
     lib.bvq_abi_version.restype = i32
     lib.bvq_last_error.restype = ctypes.c_char_p
@@ -67,6 +69,8 @@ def _load():
         'bvq_stat_bwd': (i32, [i32, i32, vp, vp, vp, vp, i64, i64, i64, i32, vp, i64, vp]),
         'bvq_fakequant_fwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp]),
         'bvq_fakequant_bwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
+        'bvq_absmax_scale': (i32, [i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
+        'bvq_running_stats_update': (i32, [i32, vp, i32, vp, i64, dbl, i32, vp]),
         'bvq_tie_info_bytes': (i64, [i64]),
         'bvq_stat_tie_scan': (i32, [i32, i32, vp, vp, i64, i64, i64, vp, vp, vp]),
         'bvq_stat_tie_apply': (i32, [i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
@@ -255,6 +259,38 @@ def fakequant_fwd(desc, x, scale, zp, want_codes=False):
         if _timer is not None:
             _timer.after('bvq_fakequant_fwd')
     return (y, codes) if want_codes else y
+
+
+def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype):
+    """abs-max statistic and the scale derived from it, one call: -> (stat [channels], scale [channels])"""
+    dev = require_device(x)
+    assert x.is_contiguous() and x.numel() == outer * channels * inner
+    dt = dtype_code(x.dtype)
+    stat = torch.empty(channels, dtype=x.dtype, device=dev)
+    scale = torch.empty(channels, dtype=scale_dtype, device=dev)
+    wsb = lib.bvq_stats_workspace_bytes(STAT_ABSMAX, dt, outer, channels, inner)
+    ws = torch.empty(max(int(wsb), 8), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        if _timer is not None:
+            _timer.before('bvq_stats')
+        check(lib.bvq_absmax_scale(dt, ptr(x), outer, channels, inner, ptr(stat), float(min_val or 0.0),
+                                   int(bool(min_val)), float(int_threshold), dtype_code(scale_dtype), ptr(scale),
+                                   ptr(ws), ws.numel(), stream_ptr(dev)), 'bvq_absmax_scale')
+        if _timer is not None:
+            _timer.after('bvq_stats')
+    return stat, scale
+
+
+def running_stats_update(running, stat, momentum, first_batch):
+    """in-place batch-norm style update of a running statistic (one launch)"""
+    dev = require_device(running, stat)
+    assert running.is_contiguous() and running.numel() == stat.numel()
+    stat = stat.contiguous()
+    with torch.cuda.device(dev):
+        check(lib.bvq_running_stats_update(dtype_code(running.dtype), ptr(running), dtype_code(stat.dtype),
+                                           ptr(stat), running.numel(), float(momentum), int(first_batch),
+                                           stream_ptr(dev)), 'bvq_running_stats_update')
+    return running
 
 
 def tie_info_buffer(channels, device):

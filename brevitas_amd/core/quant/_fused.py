@@ -126,6 +126,25 @@ class StatsPlan(NamedTuple):
     inner: int
     scaling_shape: tuple
     min_val: float
+    int_threshold: float  # host value of int_scaling_impl(bit_width)
+
+
+_ZERO_ZP = {}
+
+
+def _zero_zero_point(device):
+    """the 0-dim float32 zero the ZeroZeroPoint module returns, one per device (no fill kernel per call)"""
+    z = _ZERO_ZP.get(device)
+    if z is None:
+        z = torch.zeros((), dtype=torch.float32, device=device)
+        _ZERO_ZP[device] = z
+    return z
+
+
+def _as_dtype_value(v: float, dtype: torch.dtype) -> float:
+    """v after torch converts it to `dtype` (what a 0-dim float32 operand becomes next to a dimensioned
+    tensor of that dtype on the device)"""
+    return float(torch.tensor(v, dtype=torch.float32).to(dtype))
 
 
 class StatsFakeQuantFn(Function):
@@ -142,18 +161,27 @@ class StatsFakeQuantFn(Function):
         xc = x.contiguous()
         flat = xc.reshape(-1)
         if group is None:
-            stat = nat.stats(nat.STAT_ABSMAX, flat, sp.outer, sp.channels, sp.inner)
+            # statistic -> clamp_min -> / int_threshold in the reduction's own finishing launch.
+            # torch's promotion: a dimensioned threshold keeps its dtype (the 0-dim float32
+            # int_threshold is converted to it), a 0-dim one is promoted with float32.
+            if len(sp.scaling_shape) > 0:
+                scale_dtype, thr_div = x.dtype, _as_dtype_value(sp.int_threshold, x.dtype)
+            else:
+                scale_dtype = torch.promote_types(x.dtype, int_threshold.dtype)
+                thr_div = sp.int_threshold
+            stat, scale = nat.absmax_scale(flat, sp.outer, sp.channels, sp.inner, sp.min_val, thr_div, scale_dtype)
+            scale = scale.view(sp.scaling_shape)
         else:
             # batch-sharded tensor: the statistic of the whole batch is the max over the shards
             from brevitas_amd.distributed import sync_stat_max
             stat32 = nat.stats(nat.STAT_ABSMAX, flat, sp.outer, sp.channels, sp.inner, out_f32=True)
             stat = sync_stat_max(stat32, group).to(x.dtype)
-        # _StatsScaling with float restriction: scalar_clamp_min_ste (B/core/restrict_val.py:22-42)
-        thr = nat.scalar_clamp(stat, sp.min_val, None) if sp.min_val else stat
-        # RescalingIntQuant.forward: scale = threshold / int_threshold (B/core/quant/int.py:160),
-        # on tensors shaped like the reference's so that type promotion is the same
-        scale = thr.view(sp.scaling_shape) / int_threshold
-        zp = torch.zeros((), dtype=torch.float32, device=x.device)
+            # _StatsScaling with float restriction: scalar_clamp_min_ste (B/core/restrict_val.py:22-42)
+            thr = nat.scalar_clamp(stat, sp.min_val, None) if sp.min_val else stat
+            # RescalingIntQuant.forward: scale = threshold / int_threshold (B/core/quant/int.py:160),
+            # on tensors shaped like the reference's so that type promotion is the same
+            scale = thr.view(sp.scaling_shape) / int_threshold
+        zp = _zero_zero_point(x.device)
         p = plan(xc, scale, zp)
         if p is None:
             raise nat.BvqError('StatsFakeQuantFn: unsupported operand layout (caller must pre-check)')

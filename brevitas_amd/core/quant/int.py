@@ -87,10 +87,11 @@ class RescalingIntQuant(torch.nn.Module):
         if min_val is None or type(stats.stats_impl) is not AbsMax:
             return None
         shape = tuple(stats.stats_output_shape)
+        int_thr = self.int_scaling_impl.host_value(bit_width.bvq_host_value)
         if type(view) is OverTensorView and stats.stats_impl.stats_reduce_dim is None:
             if shape != ():
                 return None
-            return _fused.StatsPlan(1, 1, x.numel(), shape, min_val), runtime
+            return _fused.StatsPlan(1, 1, x.numel(), shape, min_val, int_thr), runtime
         if type(view) is OverOutputChannelView and stats.stats_impl.stats_reduce_dim in (1, -1):
             cd = view.bvq_channel_dim(x.dim())
             if cd is None or cd < 0:
@@ -106,7 +107,7 @@ class RescalingIntQuant(torch.nn.Module):
             inner = 1
             for s in x.shape[cd + 1:]:
                 inner *= s
-            return _fused.StatsPlan(outer, x.shape[cd], inner, shape, min_val), runtime
+            return _fused.StatsPlan(outer, x.shape[cd], inner, shape, min_val, int_thr), runtime
         return None
 
     def forward(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:

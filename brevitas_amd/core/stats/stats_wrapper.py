@@ -41,6 +41,13 @@ class _RuntimeStats(torch.nn.Module):
     def update_running_stats(self, out: Tensor) -> None:
         """fold one batch statistic into the buffer (B/core/stats/stats_wrapper.py:61-66)"""
         out = out.detach()
+        if out.is_cuda and self.running_stats.is_cuda and self.running_stats.is_contiguous() \
+                and out.shape == self.running_stats.shape:
+            # the same three in-place ops as below, with the same rounding points, in one launch
+            from brevitas_amd import _native as nat
+            nat.running_stats_update(self.running_stats, out, self.momentum, self.first_batch)
+            self.first_batch = False
+            return
         if self.first_batch:
             self.running_stats *= out
             self.first_batch = False

@@ -46,19 +46,22 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
-    stamp = os.path.join(OBJ_DIR, 'stamp')
-    dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp):
+def build(force=False, verbose=False, defines=(), out=None):
+    """defines/out: developer experiments only (tools/microbench.py --lib): extra -D flags, other output"""
+    lib_path = out or LIB
+    obj_dir = OBJ_DIR if not out else os.path.join(OBJ_DIR, os.path.basename(out).replace('.', '_'))
+    stamp = os.path.join(obj_dir, 'stamp')
+    dig = _digest() + ' ' + ' '.join(defines)
+    if not force and os.path.exists(lib_path) and os.path.exists(stamp):
         with open(stamp) as fh:
             if fh.read().strip() == dig:
-                return LIB
-    os.makedirs(OBJ_DIR, exist_ok=True)
+                return lib_path
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
 
     def compile_one(src):
-        obj = os.path.join(OBJ_DIR, src.replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        obj = os.path.join(obj_dir, src.replace('.hip', '.o'))
+        cmd = [hipcc] + FLAGS + ['-D' + d for d in defines] + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -70,15 +73,18 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB + '.tmp'] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path + '.tmp'] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
-    os.replace(LIB + '.tmp', LIB)
+    os.replace(lib_path + '.tmp', lib_path)
     with open(stamp, 'w') as fh:
         fh.write(dig)
-    return LIB
+    return lib_path
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith('-D')]
+    outs = [a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--out=')]
+    print(build(force='--force' in sys.argv, verbose='-v' in sys.argv, defines=defs,
+                out=os.path.abspath(outs[0]) if outs else None))

@@ -95,14 +95,48 @@ struct alignas(sizeof(T) * N > 16 ? 16 : sizeof(T) * N) vec_t {
   T v[N];
 };
 
-template <typename T, int N>
+// NT = non-temporal cache policy (the `nt` bit of global_load/store): for tensors far larger than the
+// 256 MiB Infinity Cache every byte is touched once per kernel, and streaming loads AND stores
+// measured -9 % on the headline step (profiles/r01_variants_*.txt).  Small tensors (weights) keep the
+// default policy so that their consumer finds them in L2 / Infinity Cache.
+template <typename T, int N, bool NT = false>
 __device__ __forceinline__ vec_t<T, N> load_vec(const T* p) {
-  return *reinterpret_cast<const vec_t<T, N>*>(p);
+  if constexpr (NT && sizeof(T) * N == 16) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return __builtin_bit_cast(vec_t<T, N>, r);
+  } else if constexpr (NT && sizeof(T) * N == 32) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    struct pair_t {
+      u32x4 a, b;
+    } r;
+    r.a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    r.b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + 1);
+    return __builtin_bit_cast(vec_t<T, N>, r);
+  } else {
+    return *reinterpret_cast<const vec_t<T, N>*>(p);
+  }
 }
-template <typename T, int N>
+template <typename T, int N, bool NT = false>
 __device__ __forceinline__ void store_vec(T* p, const vec_t<T, N>& v) {
-  *reinterpret_cast<vec_t<T, N>*>(p) = v;
+  if constexpr (NT && sizeof(T) * N == 16) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
+  } else if constexpr (NT && sizeof(T) * N == 32) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    struct pair_t {
+      u32x4 a, b;
+    };
+    const pair_t r = __builtin_bit_cast(pair_t, v);
+    __builtin_nontemporal_store(r.a, reinterpret_cast<u32x4*>(p));
+    __builtin_nontemporal_store(r.b, reinterpret_cast<u32x4*>(p) + 1);
+  } else {
+    *reinterpret_cast<vec_t<T, N>*>(p) = v;
+  }
 }
+
+// bytes a call must stream before its kernels switch to the non-temporal policy
+int64_t nt_threshold_bytes();
 
 // read element 0 / element c of a scale-like buffer of runtime dtype as float (wave-uniform use)
 __device__ __forceinline__ float load_scalar_as_f(const void* p, int dt, int64_t idx) {
@@ -142,16 +176,28 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---- tiling ------------------------------------------------------------------------------------
+// x is [outer, channels, row_len] (per-tensor: outer = channels = 1, row_len = everything).
+// A UNIT -- the work of one wave -- is  `rpu` consecutive outer indices of ONE channel  x  one
+// piece of the row:
+//   long rows  (per-tensor, big weights): rpu = 1, the row is cut into ppr pieces of piece_len;
+//   short rows (NCHW activations: H*W elements): ppr = 1 and rpu rows of the same channel are
+//     walked back to back, chosen so that rpu * (chunks per row) fills the 64 lanes of every load
+//     instruction (a 56x56 bf16 row is 392 chunks = 6.125 wave-loads; 8 rows are exactly 49).
+// unit index = (outer_block * channels + channel) * ppr + piece: neighbouring waves touch
+// neighbouring memory.
 struct Tiling {
-  int64_t rows;       // number of rows ((outer, channel) slices; 1 for per-tensor)
+  int64_t outer;      // outer extent (1 for per-tensor)
   int64_t row_len;    // elements per row
-  int64_t piece_len;  // elements per piece (multiple of the vector width)
+  int64_t piece_len;  // elements per piece (multiple of the vector width unless it is the row)
   int64_t ppr;        // pieces per row
-  int64_t units;      // rows * ppr
-  int32_t channels;   // row r belongs to channel r % channels
+  int64_t nob;        // outer blocks = ceil(outer / rpu)
+  int64_t units;      // nob * channels * ppr
+  int32_t channels;
+  int32_t rpu;        // rows (outer indices) per unit
+  int32_t reverse;    // units are visited from the end of the tensor to its start
 };
 
-// elements one wave handles per unit, in 16-byte chunks per lane.  8 chunks = 8 KiB (2-byte types).
+// elements one wave handles per piece, in 16-byte chunks per lane.  8 chunks = 8 KiB (2-byte types).
 int default_piece_chunks();
 
 // Largest power-of-two vector width (in elements, <= max_vec) usable for rows of row_len elements:
@@ -160,10 +206,89 @@ int default_piece_chunks();
 int pick_vec(int max_vec, int64_t rows, int64_t row_len, const void* const* ptrs, const int* elsizes,
              int nptr);
 
-Tiling make_tiling(int64_t rows, int64_t row_len, int32_t channels, int vec);
+Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec);
 
 static inline unsigned grid_for_units(int64_t units) {
   return (unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock);
 }
+
+#ifdef __HIPCC__
+// One wave's unit, decoded from blockIdx / wave id (wave-uniform values: scalar registers).
+struct Unit {
+  int64_t id;          // unit index (slot of its partial results)
+  int64_t base;        // element offset of the unit's first element
+  int64_t row_stride;  // elements between consecutive rows of the unit (channels * row_len)
+  int64_t len;         // elements of each row covered by this unit
+  int64_t pos0;        // position of the first element in the reference's per-channel reduction
+                       // order: (outer index) * row_len + offset in row  (flat index if per-tensor)
+  int32_t nrows;       // rows in this unit
+  int32_t channel;
+  bool valid;
+};
+
+__device__ __forceinline__ Unit locate_unit(const Tiling& t) {
+  Unit u;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  u.id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  u.valid = u.id < t.units;
+  if (t.reverse) u.id = t.units - 1 - u.id;  // walk the tensor back to front (see make_tiling)
+  if (!u.valid) {
+    u.base = u.row_stride = u.len = u.pos0 = 0;
+    u.nrows = u.channel = 0;
+    return u;
+  }
+  const int64_t rc = u.id / t.ppr;  // (outer_block, channel)
+  const int64_t piece = u.id - rc * t.ppr;
+  const int64_t ob = rc / t.channels;
+  u.channel = (int32_t)(rc - ob * t.channels);
+  const int64_t o0 = ob * t.rpu;
+  const int64_t left = t.outer - o0;
+  u.nrows = (int32_t)(left < t.rpu ? left : t.rpu);
+  const int64_t off = piece * t.piece_len;
+  const int64_t rest = t.row_len - off;
+  u.len = rest < t.piece_len ? rest : t.piece_len;
+  u.row_stride = (int64_t)t.channels * t.row_len;
+  u.base = (o0 * t.channels + u.channel) * t.row_len + off;
+  u.pos0 = o0 * t.row_len + off;
+  return u;
+}
+
+// Per-lane walk over the VEC-element chunks of a unit: chunk k of the unit (k = lane, lane+64, ...)
+// lives in row k / cpr at chunk k % cpr; the walk advances by 64 chunks without dividing.
+struct ChunkCursor {
+  int32_t row;    // row inside the unit
+  int32_t chunk;  // chunk inside the row
+  int32_t cpr;    // full chunks per row
+  int32_t nrows;
+  __device__ __forceinline__ void init(const Unit& u, int vec, int lane) {
+    cpr = (int32_t)(u.len / vec);
+    nrows = u.nrows;
+    if (nrows == 1 || cpr == 0) {
+      row = 0;
+      chunk = lane;
+    } else {
+      row = lane / cpr;
+      chunk = lane - row * cpr;
+    }
+  }
+  __device__ __forceinline__ bool valid() const { return nrows == 1 ? chunk < cpr : row < nrows; }
+  __device__ __forceinline__ void next() {
+    chunk += kWave;
+    if (nrows != 1) {
+      while (chunk >= cpr && row < nrows) {
+        chunk -= cpr;
+        ++row;
+      }
+    }
+  }
+  // element offset from the unit's base / from pos0
+  __device__ __forceinline__ int64_t offset(int64_t row_stride, int vec) const {
+    return (int64_t)row * row_stride + (int64_t)chunk * vec;
+  }
+  __device__ __forceinline__ int64_t pos(int64_t row_len, int vec) const {
+    return (int64_t)row * row_len + (int64_t)chunk * vec;
+  }
+};
+#endif
 
 }  // namespace bvq

@@ -52,6 +52,15 @@ int pick_vec(int max_vec, int64_t rows, int64_t row_len, const void* const* ptrs
   return vec;
 }
 
+int64_t nt_threshold_bytes() {
+  static int64_t v = [] {
+    const char* e = getenv("BVQ_NT_BYTES");  // experiments only
+    const long long n = e ? atoll(e) : -1;
+    return n >= 0 ? (int64_t)n : (int64_t)256 << 20;  // the Infinity Cache size
+  }();
+  return v;
+}
+
 int max_units_per_channel() {
   static int v = [] {
     const char* e = getenv("BVQ_MAX_UNITS_PER_CHANNEL");
@@ -61,29 +70,48 @@ int max_units_per_channel() {
   return v;
 }
 
-Tiling make_tiling(int64_t rows, int64_t row_len, int32_t channels, int vec) {
+Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec) {
   Tiling t;
-  t.rows = rows;
-  t.row_len = row_len;
+  t.outer = outer;
   t.channels = channels;
+  t.row_len = row_len;
   const int64_t quantum = (int64_t)kWave * vec;  // one 16-byte load per lane
   int64_t piece = (int64_t)default_piece_chunks() * quantum;
-  // keep the number of units per channel bounded: per-unit partials are combined by one workgroup
-  // per channel, and very long rows (per-tensor quantizers) otherwise produce ~1e5 partials
-  const int64_t outer = channels > 0 ? rows / channels : rows;
-  int64_t max_ppr = max_units_per_channel() / (outer > 0 ? outer : 1);
-  if (max_ppr < 1) max_ppr = 1;
-  if (row_len > piece * max_ppr) {
-    piece = (row_len + max_ppr - 1) / max_ppr;
-    piece = ((piece + quantum - 1) / quantum) * quantum;
-  }
-  if (piece > row_len) {
-    piece = row_len > 0 ? row_len : 1;
-    piece = ((piece + vec - 1) / vec) * vec;
+  t.rpu = 1;
+  t.reverse = 0;
+  if (row_len >= piece) {
+    // long rows: cut them.  Keep the number of units per channel bounded: per-unit partials are
+    // combined by one workgroup per channel, and a per-tensor quantizer is one very long row.
+    int64_t max_ppr = max_units_per_channel() / (outer > 0 ? outer : 1);
+    if (max_ppr < 1) max_ppr = 1;
+    if (row_len > piece * max_ppr) {
+      piece = (row_len + max_ppr - 1) / max_ppr;
+      piece = ((piece + quantum - 1) / quantum) * quantum;
+    }
+  } else {
+    // short rows: one piece per row, several rows of one channel per unit.  Pick the row count that
+    // wastes the fewest lanes of the 64-wide loads, within ~8 pieces worth of work per unit.
+    piece = row_len > 0 ? ((row_len + vec - 1) / vec) * vec : vec;
+    const int64_t cpr = row_len / vec;  // full chunks per row
+    if (cpr > 0 && outer > 1) {
+      const int64_t cap_chunks = 8 * (int64_t)default_piece_chunks() * kWave;
+      int64_t best = 1;
+      double best_eff = 0.0;
+      for (int64_t r = 1; r <= outer && r <= 64 && r * cpr <= cap_chunks; ++r) {
+        const int64_t loads = (r * cpr + kWave - 1) / kWave;
+        const double eff = (double)(r * cpr) / (double)(loads * kWave);
+        if (eff > best_eff + 1e-9) {
+          best_eff = eff;
+          best = r;
+        }
+      }
+      t.rpu = (int32_t)best;
+    }
   }
   t.piece_len = piece;
   t.ppr = row_len > 0 ? (row_len + piece - 1) / piece : 0;
-  t.units = rows * t.ppr;
+  t.nob = (outer + t.rpu - 1) / t.rpu;
+  t.units = t.nob * channels * t.ppr;
   return t;
 }
 

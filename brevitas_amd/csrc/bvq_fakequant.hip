@@ -23,7 +23,6 @@ struct QuantArgs {
   float* dzp_part;  // bwd only, per-unit partial of dzp
   const void* tie_stat;          // bwd only: abs-max statistic (dtype of x) whose ties are recorded
   unsigned long long* tie_info;  // bwd only (bvq_ties.h)
-  int64_t inner;                 // bwd/ties: elements per row of the [outer, channels, inner] view
   float qmin, qmax;
   int32_t scale_dtype, zp_dtype;
   int32_t scale_pc, zp_pc;
@@ -33,36 +32,14 @@ struct QuantArgs {
   int32_t round_mode;
 };
 
-constexpr int kUnroll = 4;  // 16-byte loads in flight per lane before arithmetic starts
-
-struct UnitInfo {
-  int64_t start;    // first element
-  int64_t len;      // elements in this unit
-  int64_t row;      // (outer, channel) row
-  int64_t row_off;  // offset of the unit inside its row
-  int32_t channel;
-  bool valid;
-};
-
-__device__ __forceinline__ UnitInfo locate_unit(const Tiling& t) {
-  UnitInfo u;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  u.valid = unit < t.units;
-  if (!u.valid) {
-    u.start = u.len = u.row = u.row_off = 0;
-    u.channel = 0;
-    return u;
-  }
-  u.row = unit / t.ppr;
-  const int64_t piece = unit - u.row * t.ppr;
-  u.row_off = piece * t.piece_len;
-  u.start = u.row * t.row_len + u.row_off;
-  const int64_t rest = t.row_len - u.row_off;
-  u.len = rest < t.piece_len ? rest : t.piece_len;
-  u.channel = (int32_t)(u.row % t.channels);
-  return u;
-}
+#ifndef BVQ_FWD_UNROLL
+#define BVQ_FWD_UNROLL 4
+#endif
+#ifndef BVQ_BWD_UNROLL
+#define BVQ_BWD_UNROLL 2
+#endif
+constexpr int kUnroll = BVQ_FWD_UNROLL;     // forward: 16-byte loads of x in flight per lane before arithmetic
+constexpr int kBwdUnroll = BVQ_BWD_UNROLL;  // backward: the same for each of its two input streams (x, g)
 
 template <typename CT>
 __device__ __forceinline__ void load_scale_zp(const QuantArgs& a, int32_t channel, float& s, float& z) {
@@ -127,46 +104,54 @@ __device__ __forceinline__ float fwd_elem(float xf, const Div& div, float s, flo
   return ZP0 ? rnd<CT>(q * s) : rnd<CT>(rnd<CT>(q - z) * s);  // (y_int - zero_point) * scale :93-94
 }
 
-template <typename XT, typename CT, int VEC, int RM, bool ZP0, typename Div>
-__device__ __forceinline__ void fwd_unit(const QuantArgs& a, const UnitInfo& u, const Div& div, float s,
+template <typename XT, typename CT, int VEC, int RM, bool NT, bool ZP0, typename Div>
+__device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, const Div& div, float s,
                                          float z, float qmin, float qmax) {
   const int lane = threadIdx.x & 63;
-  const XT* __restrict__ xp = reinterpret_cast<const XT*>(a.x) + u.start;
-  CT* __restrict__ yp = reinterpret_cast<CT*>(a.y) + u.start;
-  int32_t* __restrict__ cp = a.codes ? a.codes + u.start : nullptr;
+  const XT* __restrict__ xp = reinterpret_cast<const XT*>(a.x) + u.base;
+  CT* __restrict__ yp = reinterpret_cast<CT*>(a.y) + u.base;
+  int32_t* __restrict__ cp = a.codes ? a.codes + u.base : nullptr;
   const bool out_int = a.out_int != 0;
   const int mode = a.round_mode;
 
-  const int64_t nvec = u.len / VEC;
-  for (int64_t base = 0; base < nvec; base += (int64_t)kWave * kUnroll) {
+  ChunkCursor cur;
+  cur.init(u, VEC, lane);
+  const int64_t total = (int64_t)u.nrows * cur.cpr;
+  for (int64_t done = 0; done < total; done += (int64_t)kWave * kUnroll) {
     vec_t<XT, VEC> xv[kUnroll];
+    int64_t off[kUnroll];
+    bool ok[kUnroll];
 #pragma unroll
     for (int j = 0; j < kUnroll; ++j) {
-      const int64_t i = base + (int64_t)j * kWave + lane;
-      if (i < nvec) xv[j] = load_vec<XT, VEC>(xp + i * VEC);
+      ok[j] = cur.valid();
+      off[j] = cur.offset(u.row_stride, VEC);
+      if (ok[j]) xv[j] = load_vec<XT, VEC, NT>(xp + off[j]);
+      cur.next();
     }
 #pragma unroll
     for (int j = 0; j < kUnroll; ++j) {
-      const int64_t i = base + (int64_t)j * kWave + lane;
-      if (i < nvec) {
+      if (ok[j]) {
         vec_t<CT, VEC> yv;
-        vec_t<int32_t, VEC> cv;
+        float qv[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          float q;
           const float r =
-              fwd_elem<CT, RM, ZP0>(to_f<XT>(xv[j].v[k]), div, s, z, qmin, qmax, out_int, mode, q);
-          cv.v[k] = (int32_t)q;
+              fwd_elem<CT, RM, ZP0>(to_f<XT>(xv[j].v[k]), div, s, z, qmin, qmax, out_int, mode, qv[k]);
           yv.v[k] = from_f<CT>(r);
         }
-        store_vec<CT, VEC>(yp + i * VEC, yv);
-        if (cp) store_vec<int32_t, VEC>(cp + i * VEC, cv);
+        store_vec<CT, VEC, NT>(yp + off[j], yv);
+        if (cp) {  // parity / export mode only
+          vec_t<int32_t, VEC> cv;
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) cv.v[k] = (int32_t)qv[k];
+          store_vec<int32_t, VEC>(cp + off[j], cv);
+        }
       }
     }
   }
   // ragged end (only the last piece of a single-row tensor can have one)
-  const int64_t i = nvec * VEC + lane;
-  if (i < u.len) {
+  const int64_t i = (int64_t)cur.cpr * VEC + lane;
+  if (u.nrows == 1 && i < u.len) {
     float q;
     const float r = fwd_elem<CT, RM, ZP0>(to_f<XT>(xp[i]), div, s, z, qmin, qmax, out_int, mode, q);
     yp[i] = from_f<CT>(r);
@@ -174,9 +159,9 @@ __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const UnitInfo& u, 
   }
 }
 
-template <typename XT, typename CT, int VEC, int RM>
+template <typename XT, typename CT, int VEC, int RM, bool NT>
 __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
-  const UnitInfo u = locate_unit(a.t);
+  const Unit u = locate_unit(a.t);
   if (!u.valid) return;
   float s, z;
   load_scale_zp<CT>(a, u.channel, s, z);
@@ -184,11 +169,11 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
   const float qmin = rnd<CT>(a.qmin), qmax = rnd<CT>(a.qmax);
   if constexpr (elem<CT>::id == BVQ_BF16) {
     if (bf16_fast_ok(s, z)) {
-      fwd_unit<XT, CT, VEC, RM, true>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
+      fwd_unit<XT, CT, VEC, RM, NT, true>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
       return;
     }
   }
-  fwd_unit<XT, CT, VEC, RM, false>(a, u, DivExact{s}, s, z, qmin, qmax);
+  fwd_unit<XT, CT, VEC, RM, NT, false>(a, u, DivExact{s}, s, z, qmin, qmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -228,113 +213,118 @@ __device__ __forceinline__ float bwd_elem(float xf, float gf, const Div& div, fl
   return dxv;
 }
 
-template <typename XT, typename CT, int VEC, int RM, int MODE, bool ZP0, typename Div>
-__device__ __forceinline__ void bwd_unit(const QuantArgs& a, const UnitInfo& u, const Div& div, float s,
+template <typename XT, typename CT, int VEC, int RM, int MODE, bool NT, bool ZP0, typename Div>
+__device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, const Div& div, float s,
                                          float z, float qmin, float qmax) {
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool clamp_ste = a.clamp_ste != 0;
   const int mode = a.round_mode;
-  const XT* __restrict__ xp = reinterpret_cast<const XT*>(a.x) + u.start;
-  const CT* __restrict__ gp = reinterpret_cast<const CT*>(a.g) + u.start;
-  XT* __restrict__ dxp = reinterpret_cast<XT*>(a.y) + u.start;
+  const XT* __restrict__ xp = reinterpret_cast<const XT*>(a.x) + u.base;
+  const CT* __restrict__ gp = reinterpret_cast<const CT*>(a.g) + u.base;
+  XT* __restrict__ dxp = reinterpret_cast<XT*>(a.y) + u.base;
 
-  // abs-max tie search: position of this unit's first element in the reference's reduction order
-  // of its channel ((outer index) * inner + offset in the row), or the flat index (per-tensor)
+  // abs-max tie search: |x| == statistic of this unit's channel
   uint32_t stat_bits = 0;
-  int64_t pos0 = 0;
   const bool per_channel = a.t.channels > 1;
-  if constexpr (MODE == kBwdDsTies) {
+  if constexpr (MODE == kBwdDsTies)
     stat_bits = abs_bits<XT>(reinterpret_cast<const XT*>(a.tie_stat)[u.channel]);
-    pos0 = per_channel ? (u.row / a.t.channels) * a.inner + u.row_off : u.start;
-  }
 
   float ds_acc = 0.f, dzp_acc = 0.f;
-  constexpr int kU = kUnroll / 2 > 0 ? kUnroll / 2 : 1;  // two input streams
-  const int64_t nvec = u.len / VEC;
-  for (int64_t base = 0; base < nvec; base += (int64_t)kWave * kU) {
+  constexpr int kU = kBwdUnroll;  // chunks per lane in flight, for each of the two input streams
+  ChunkCursor cur;
+  cur.init(u, VEC, lane);
+  const int64_t total = (int64_t)u.nrows * cur.cpr;
+  for (int64_t done = 0; done < total; done += (int64_t)kWave * kU) {
     vec_t<XT, VEC> xv[kU];
     vec_t<CT, VEC> gv[kU];
+    int64_t off[kU];
+    int64_t pos[kU];
+    bool ok[kU];
 #pragma unroll
     for (int j = 0; j < kU; ++j) {
-      const int64_t i = base + (int64_t)j * kWave + lane;
-      if (i < nvec) {
-        xv[j] = load_vec<XT, VEC>(xp + i * VEC);
-        gv[j] = load_vec<CT, VEC>(gp + i * VEC);
+      ok[j] = cur.valid();
+      off[j] = cur.offset(u.row_stride, VEC);
+      if constexpr (MODE == kBwdDsTies) pos[j] = u.pos0 + cur.pos(a.t.row_len, VEC);
+      if (ok[j]) {
+        xv[j] = load_vec<XT, VEC, NT>(xp + off[j]);
+        gv[j] = load_vec<CT, VEC, NT>(gp + off[j]);
       }
+      cur.next();
     }
 #pragma unroll
     for (int j = 0; j < kU; ++j) {
-      const int64_t i = base + (int64_t)j * kWave + lane;
-      if (i < nvec) {
+      if (ok[j]) {
         vec_t<XT, VEC> dv;
-        bool any_tie = false;
+        uint32_t mx = 0;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           const float d =
               bwd_elem<CT, RM, MODE, ZP0>(to_f<XT>(xv[j].v[k]), to_f<CT>(gv[j].v[k]), div, s, z, qmin,
                                           qmax, clamp_ste, mode, ds_acc, dzp_acc);
           dv.v[k] = from_f<XT>(d);
-          if constexpr (MODE == kBwdDsTies) any_tie |= abs_bits<XT>(xv[j].v[k]) == stat_bits;
+          if constexpr (MODE == kBwdDsTies) {
+            // cheap chunk-level filter: a tie in this chunk needs the chunk's max |x| to reach the statistic
+            const uint32_t b = abs_bits<XT>(xv[j].v[k]);
+            mx = b > mx ? b : mx;
+          }
         }
-        store_vec<XT, VEC>(dxp + i * VEC, dv);
+        store_vec<XT, VEC, NT>(dxp + off[j], dv);
         if constexpr (MODE == kBwdDsTies) {
-          if (any_tie) {  // rare: at most a handful of elements per channel attain the maximum
+          if (mx >= stat_bits) {  // rare: a handful of elements per channel attain the maximum
             for (int k = 0; k < VEC; ++k)
               if (abs_bits<XT>(xv[j].v[k]) == stat_bits)
-                record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(pos0 + i * VEC + k));
+                record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(pos[j] + k));
           }
         }
       }
     }
   }
-  const int64_t i = nvec * VEC + lane;
-  if (i < u.len) {
+  const int64_t i = (int64_t)cur.cpr * VEC + lane;
+  if (u.nrows == 1 && i < u.len) {
     const float d = bwd_elem<CT, RM, MODE, ZP0>(to_f<XT>(xp[i]), to_f<CT>(gp[i]), div, s, z, qmin, qmax,
                                                 clamp_ste, mode, ds_acc, dzp_acc);
     dxp[i] = from_f<XT>(d);
     if constexpr (MODE == kBwdDsTies) {
       if (abs_bits<XT>(xp[i]) == stat_bits)
-        record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(pos0 + i));
+        record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(u.pos0 + i));
     }
   }
   if constexpr (MODE >= kBwdDs) {
-    const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     ds_acc = wave_sum(ds_acc);
-    if (lane == 0) a.ds_part[unit] = ds_acc;
+    if (lane == 0) a.ds_part[u.id] = ds_acc;
     if constexpr (MODE == kBwdDsDzp) {
       dzp_acc = wave_sum(dzp_acc);
-      if (lane == 0) a.dzp_part[unit] = dzp_acc;
+      if (lane == 0) a.dzp_part[u.id] = dzp_acc;
     }
   }
 }
 
-template <typename XT, typename CT, int VEC, int RM, int MODE>
+template <typename XT, typename CT, int VEC, int RM, int MODE, bool NT>
 __global__ __launch_bounds__(kBlock) void fakequant_bwd_kernel(QuantArgs a) {
-  const UnitInfo u = locate_unit(a.t);
+  const Unit u = locate_unit(a.t);
   if (!u.valid) return;
   float s, z;
   load_scale_zp<CT>(a, u.channel, s, z);
   const float qmin = rnd<CT>(a.qmin), qmax = rnd<CT>(a.qmax);
   if constexpr (elem<CT>::id == BVQ_BF16) {
     if (bf16_fast_ok(s, z)) {
-      bwd_unit<XT, CT, VEC, RM, MODE, true>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
+      bwd_unit<XT, CT, VEC, RM, MODE, NT, true>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
       return;
     }
   }
-  bwd_unit<XT, CT, VEC, RM, MODE, false>(a, u, DivExact{s}, s, z, qmin, qmax);
+  bwd_unit<XT, CT, VEC, RM, MODE, NT, false>(a, u, DivExact{s}, s, z, qmin, qmax);
 }
 
 // Combine per-unit partial sums of one channel in a fixed order (double accumulation):
-// channel c owns units (o*channels + c)*ppr + p for o in [0, outer), p in [0, ppr).
+// channel c owns units (ob*channels + c)*ppr + p for ob in [0, nob), p in [0, ppr).
 __global__ __launch_bounds__(kBlock) void channel_sum_kernel(const float* __restrict__ part0,
                                                              const float* __restrict__ part1,
                                                              float* __restrict__ out0,
-                                                             float* __restrict__ out1, int64_t outer,
+                                                             float* __restrict__ out1, int64_t nob,
                                                              int32_t channels, int64_t ppr) {
   __shared__ double sh[2][kBlock];
   const int32_t c = blockIdx.x;
-  const int64_t n = outer * ppr;
+  const int64_t n = nob * ppr;
   double acc0 = 0.0, acc1 = 0.0;
   for (int64_t k = threadIdx.x; k < n; k += kBlock) {
     const int64_t o = k / ppr, p = k - o * ppr;
@@ -389,15 +379,15 @@ static int validate(const bvq_quant_desc* d) {
   return BVQ_OK;
 }
 
-// rows/row_len of the descriptor: per-tensor quantizers are one long row
-static void rows_of(const bvq_quant_desc* d, int64_t& rows, int64_t& row_len, int32_t& channels) {
+// [outer, channels, row_len] of the descriptor: per-tensor quantizers are one long row
+static void rows_of(const bvq_quant_desc* d, int64_t& outer, int64_t& row_len, int32_t& channels) {
   const bool pc = (d->scale_per_channel || d->zp_per_channel) && d->channels > 1;
   if (pc) {
-    rows = d->outer * d->channels;
+    outer = d->outer;
     row_len = d->inner;
     channels = (int32_t)d->channels;
   } else {
-    rows = 1;
+    outer = 1;
     row_len = d->outer * d->channels * d->inner;
     channels = 1;
   }
@@ -420,55 +410,63 @@ static void fill_args(QuantArgs& a, const bvq_quant_desc* d) {
 static int snap_vec(int vec, int full) { return vec == full ? full : 1; }
 
 template <typename XT, typename CT>
-static void launch_fwd(const QuantArgs& a, int vec, hipStream_t st) {
+static void launch_fwd(const QuantArgs& a, int vec, bool nt, hipStream_t st) {
   constexpr int V = elem<XT>::vec;
   const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
   const bool rne = a.round_mode == BVQ_ROUND;
   if (vec == V) {
-    if (rne)
-      fakequant_fwd_kernel<XT, CT, V, BVQ_ROUND><<<grid, block, 0, st>>>(a);
+    if (rne && nt)
+      fakequant_fwd_kernel<XT, CT, V, BVQ_ROUND, true><<<grid, block, 0, st>>>(a);
+    else if (rne)
+      fakequant_fwd_kernel<XT, CT, V, BVQ_ROUND, false><<<grid, block, 0, st>>>(a);
+    else if (nt)
+      fakequant_fwd_kernel<XT, CT, V, kAnyRM, true><<<grid, block, 0, st>>>(a);
     else
-      fakequant_fwd_kernel<XT, CT, V, kAnyRM><<<grid, block, 0, st>>>(a);
+      fakequant_fwd_kernel<XT, CT, V, kAnyRM, false><<<grid, block, 0, st>>>(a);
   } else {
     if (rne)
-      fakequant_fwd_kernel<XT, CT, 1, BVQ_ROUND><<<grid, block, 0, st>>>(a);
+      fakequant_fwd_kernel<XT, CT, 1, BVQ_ROUND, false><<<grid, block, 0, st>>>(a);
     else
-      fakequant_fwd_kernel<XT, CT, 1, kAnyRM><<<grid, block, 0, st>>>(a);
+      fakequant_fwd_kernel<XT, CT, 1, kAnyRM, false><<<grid, block, 0, st>>>(a);
   }
 }
 
 template <typename XT, typename CT, int MODE>
-static void launch_bwd_mode(const QuantArgs& a, int vec, hipStream_t st) {
+static void launch_bwd_mode(const QuantArgs& a, int vec, bool nt, hipStream_t st) {
   constexpr int V = elem<XT>::vec;
   const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
   const bool rne = a.round_mode == BVQ_ROUND;
   if (vec == V) {
-    if (rne)
-      fakequant_bwd_kernel<XT, CT, V, BVQ_ROUND, MODE><<<grid, block, 0, st>>>(a);
+    if (rne && nt)
+      fakequant_bwd_kernel<XT, CT, V, BVQ_ROUND, MODE, true><<<grid, block, 0, st>>>(a);
+    else if (rne)
+      fakequant_bwd_kernel<XT, CT, V, BVQ_ROUND, MODE, false><<<grid, block, 0, st>>>(a);
+    else if (nt)
+      fakequant_bwd_kernel<XT, CT, V, kAnyRM, MODE, true><<<grid, block, 0, st>>>(a);
     else
-      fakequant_bwd_kernel<XT, CT, V, kAnyRM, MODE><<<grid, block, 0, st>>>(a);
+      fakequant_bwd_kernel<XT, CT, V, kAnyRM, MODE, false><<<grid, block, 0, st>>>(a);
   } else {
     if (rne)
-      fakequant_bwd_kernel<XT, CT, 1, BVQ_ROUND, MODE><<<grid, block, 0, st>>>(a);
+      fakequant_bwd_kernel<XT, CT, 1, BVQ_ROUND, MODE, false><<<grid, block, 0, st>>>(a);
     else
-      fakequant_bwd_kernel<XT, CT, 1, kAnyRM, MODE><<<grid, block, 0, st>>>(a);
+      fakequant_bwd_kernel<XT, CT, 1, kAnyRM, MODE, false><<<grid, block, 0, st>>>(a);
   }
 }
 
 template <typename XT, typename CT>
-static void launch_bwd(const QuantArgs& a, int vec, int mode, hipStream_t st) {
+static void launch_bwd(const QuantArgs& a, int vec, int mode, bool nt, hipStream_t st) {
   switch (mode) {
     case kBwdDx:
-      launch_bwd_mode<XT, CT, kBwdDx>(a, vec, st);
+      launch_bwd_mode<XT, CT, kBwdDx>(a, vec, nt, st);
       break;
     case kBwdDs:
-      launch_bwd_mode<XT, CT, kBwdDs>(a, vec, st);
+      launch_bwd_mode<XT, CT, kBwdDs>(a, vec, nt, st);
       break;
     case kBwdDsDzp:
-      launch_bwd_mode<XT, CT, kBwdDsDzp>(a, vec, st);
+      launch_bwd_mode<XT, CT, kBwdDsDzp>(a, vec, nt, st);
       break;
     default:
-      launch_bwd_mode<XT, CT, kBwdDsTies>(a, vec, st);
+      launch_bwd_mode<XT, CT, kBwdDsTies>(a, vec, nt, st);
       break;
   }
 }
@@ -502,15 +500,15 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
     set_error("bvq_fakequant_fwd: null pointer");
     return BVQ_ERR_INVALID;
   }
-  int64_t rows, row_len;
+  int64_t outer, row_len;
   int32_t channels;
-  rows_of(d, rows, row_len, channels);
+  rows_of(d, outer, row_len, channels);
   const void* ptrs[3] = {x, y, codes};
   const int els[3] = {dtype_size(d->x_dtype), dtype_size(d->ct_dtype), 4};
   const int full = 16 / dtype_size(d->x_dtype);
-  const int vec = snap_vec(pick_vec(full, rows, row_len, ptrs, els, 3), full);
+  const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3), full);
   QuantArgs a = {};
-  a.t = make_tiling(rows, row_len, channels, vec);
+  a.t = make_tiling(outer, channels, row_len, vec);
   a.x = x;
   a.scale = scale;
   a.zp = zp;
@@ -518,20 +516,21 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
   a.codes = codes;
   fill_args(a, d);
   hipStream_t st = (hipStream_t)stream;
-#define BVQ_CALL(XT, CT) launch_fwd<XT, CT>(a, vec, st)
+  const bool nt = n * (int64_t)(dtype_size(d->x_dtype) + dtype_size(d->ct_dtype)) >= nt_threshold_bytes();
+#define BVQ_CALL(XT, CT) launch_fwd<XT, CT>(a, vec, nt, st)
   BVQ_DISPATCH_PAIR(d, BVQ_CALL);
 #undef BVQ_CALL
   return check_launch("bvq_fakequant_fwd");
 }
 
 static int64_t bwd_units(const bvq_quant_desc* d) {
-  int64_t rows, row_len;
+  int64_t outer, row_len;
   int32_t channels;
-  rows_of(d, rows, row_len, channels);
+  rows_of(d, outer, row_len, channels);
   // upper bound over the vector widths the launcher may pick
   const int full = 16 / dtype_size(d->x_dtype);
-  const int64_t a = make_tiling(rows, row_len, channels, full).units;
-  const int64_t b = make_tiling(rows, row_len, channels, 1).units;
+  const int64_t a = make_tiling(outer, channels, row_len, full).units;
+  const int64_t b = make_tiling(outer, channels, row_len, 1).units;
   return a > b ? a : b;
 }
 
@@ -548,9 +547,9 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   if (rc) return rc;
   const int64_t n = d->outer * d->channels * d->inner;
   hipStream_t st = (hipStream_t)stream;
-  int64_t rows, row_len;
+  int64_t outer, row_len;
   int32_t channels;
-  rows_of(d, rows, row_len, channels);
+  rows_of(d, outer, row_len, channels);
   const bool need_sums = dscale != nullptr || dzp != nullptr;
   if ((tie_stat != nullptr) != (tie_info != nullptr)) {
     set_error("bvq_fakequant_bwd: tie_stat and tie_info go together");
@@ -578,9 +577,9 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   const void* ptrs[3] = {x, g, dx};
   const int els[3] = {dtype_size(d->x_dtype), dtype_size(d->ct_dtype), dtype_size(d->x_dtype)};
   const int full = 16 / dtype_size(d->x_dtype);
-  const int vec = snap_vec(pick_vec(full, rows, row_len, ptrs, els, 3), full);
+  const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3), full);
   QuantArgs a = {};
-  a.t = make_tiling(rows, row_len, channels, vec);
+  a.t = make_tiling(outer, channels, row_len, vec);
   if (need_sums) {
     const int64_t need = 2 * a.t.units * (int64_t)sizeof(float);
     if (!workspace || workspace_bytes < need) {
@@ -598,20 +597,18 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   a.y = dx;
   a.tie_stat = tie_stat;
   a.tie_info = reinterpret_cast<unsigned long long*>(tie_info);
-  a.inner = d->inner;
   fill_args(a, d);
   const int mode = tie_stat ? kBwdDsTies : (dzp ? kBwdDsDzp : (dscale ? kBwdDs : kBwdDx));
-#define BVQ_CALL(XT, CT) launch_bwd<XT, CT>(a, vec, mode, st)
+  const bool nt =
+      n * (int64_t)(2 * dtype_size(d->x_dtype) + dtype_size(d->ct_dtype)) >= nt_threshold_bytes();
+#define BVQ_CALL(XT, CT) launch_bwd<XT, CT>(a, vec, mode, nt, st)
   BVQ_DISPATCH_PAIR(d, BVQ_CALL);
 #undef BVQ_CALL
   rc = check_launch("bvq_fakequant_bwd");
   if (rc) return rc;
   if (need_sums) {
-    // per-tensor quantizers have one "channel" spanning every unit
-    const int64_t outer_rows = rows / channels;
     channel_sum_kernel<<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(
-        dscale ? a.ds_part : nullptr, dzp ? a.dzp_part : nullptr, dscale, dzp, outer_rows, channels,
-        a.t.ppr);
+        dscale ? a.ds_part : nullptr, dzp ? a.dzp_part : nullptr, dscale, dzp, a.t.nob, channels, a.t.ppr);
     rc = check_launch("bvq_fakequant_bwd/channel_sum");
   }
   return rc;

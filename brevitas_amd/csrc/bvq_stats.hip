@@ -8,6 +8,9 @@
 // abs-max works on the raw bit patterns: for |x| the IEEE order equals the unsigned-integer order
 // of (bits & ~sign), and every NaN pattern is larger than +inf, so an unsigned max IS
 // torch.max(torch.abs(x)) including its NaN propagation.  The result is exact (a max never rounds).
+#include <math.h>
+#include <string.h>
+
 #include "bvq_common.h"
 #include "bvq_ties.h"
 
@@ -22,41 +25,28 @@ struct StatArgs {
   uint32_t* part_b;  // MINMAX: min as float bits
 };
 
-__device__ __forceinline__ bool locate(const Tiling& t, int64_t& unit, int64_t& start, int64_t& len,
-                                       int32_t& channel, int64_t& row_off) {
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  if (unit >= t.units) return false;
-  const int64_t row = unit / t.ppr;
-  const int64_t piece = unit - row * t.ppr;
-  row_off = piece * t.piece_len;
-  start = row * t.row_len + row_off;
-  const int64_t rest = t.row_len - row_off;
-  len = rest < t.piece_len ? rest : t.piece_len;
-  channel = (int32_t)(row % t.channels);
-  return true;
-}
-
-template <typename T, int VEC>
+template <typename T, int VEC, bool NT>
 __global__ __launch_bounds__(kBlock) void absmax_kernel(StatArgs a) {
-  int64_t unit, start, len, row_off;
-  int32_t channel;
-  if (!locate(a.t, unit, start, len, channel, row_off)) return;
+  const Unit u = locate_unit(a.t);
+  if (!u.valid) return;
   const int lane = threadIdx.x & 63;
-  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + start;
+  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + u.base;
   uint32_t m = 0;
-  const int64_t nvec = len / VEC;
-  for (int64_t base = 0; base < nvec; base += (int64_t)kWave * kStatUnroll) {
+  ChunkCursor cur;
+  cur.init(u, VEC, lane);
+  const int64_t total = (int64_t)u.nrows * cur.cpr;
+  for (int64_t done = 0; done < total; done += (int64_t)kWave * kStatUnroll) {
     vec_t<T, VEC> xv[kStatUnroll];
+    bool ok[kStatUnroll];
 #pragma unroll
     for (int j = 0; j < kStatUnroll; ++j) {
-      const int64_t i = base + (int64_t)j * kWave + lane;
-      if (i < nvec) xv[j] = load_vec<T, VEC>(xp + i * VEC);
+      ok[j] = cur.valid();
+      if (ok[j]) xv[j] = load_vec<T, VEC, NT>(xp + cur.offset(u.row_stride, VEC));
+      cur.next();
     }
 #pragma unroll
     for (int j = 0; j < kStatUnroll; ++j) {
-      const int64_t i = base + (int64_t)j * kWave + lane;
-      if (i < nvec) {
+      if (ok[j]) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           const uint32_t b = abs_bits<T>(xv[j].v[k]);
@@ -65,36 +55,39 @@ __global__ __launch_bounds__(kBlock) void absmax_kernel(StatArgs a) {
       }
     }
   }
-  const int64_t i = nvec * VEC + lane;
-  if (i < len) {
+  // ragged end (single-row units only)
+  const int64_t i = (int64_t)cur.cpr * VEC + lane;
+  if (u.nrows == 1 && i < u.len) {
     const uint32_t b = abs_bits<T>(xp[i]);
     m = b > m ? b : m;
   }
   m = wave_max_u32(m);
-  if (lane == 0) a.part_a[unit] = m;
+  if (lane == 0) a.part_a[u.id] = m;
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool NT>
 __global__ __launch_bounds__(kBlock) void minmax_kernel(StatArgs a) {
-  int64_t unit, start, len, row_off;
-  int32_t channel;
-  if (!locate(a.t, unit, start, len, channel, row_off)) return;
+  const Unit u = locate_unit(a.t);
+  if (!u.valid) return;
   const int lane = threadIdx.x & 63;
-  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + start;
+  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + u.base;
   float mx = -__builtin_inff(), mn = __builtin_inff();
   uint32_t nan = 0;
-  const int64_t nvec = len / VEC;
-  for (int64_t base = 0; base < nvec; base += (int64_t)kWave * kStatUnroll) {
+  ChunkCursor cur;
+  cur.init(u, VEC, lane);
+  const int64_t total = (int64_t)u.nrows * cur.cpr;
+  for (int64_t done = 0; done < total; done += (int64_t)kWave * kStatUnroll) {
     vec_t<T, VEC> xv[kStatUnroll];
+    bool ok[kStatUnroll];
 #pragma unroll
     for (int j = 0; j < kStatUnroll; ++j) {
-      const int64_t i = base + (int64_t)j * kWave + lane;
-      if (i < nvec) xv[j] = load_vec<T, VEC>(xp + i * VEC);
+      ok[j] = cur.valid();
+      if (ok[j]) xv[j] = load_vec<T, VEC, NT>(xp + cur.offset(u.row_stride, VEC));
+      cur.next();
     }
 #pragma unroll
     for (int j = 0; j < kStatUnroll; ++j) {
-      const int64_t i = base + (int64_t)j * kWave + lane;
-      if (i < nvec) {
+      if (ok[j]) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           const float f = to_f<T>(xv[j].v[k]);
@@ -105,8 +98,8 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(StatArgs a) {
       }
     }
   }
-  const int64_t i = nvec * VEC + lane;
-  if (i < len) {
+  const int64_t i = (int64_t)cur.cpr * VEC + lane;
+  if (u.nrows == 1 && i < u.len) {
     const float f = to_f<T>(xp[i]);
     nan |= (f != f) ? 1u : 0u;
     mx = fmaxf(mx, f);
@@ -117,8 +110,8 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(StatArgs a) {
   nan = wave_or_u32(nan);
   if (lane == 0) {
     // torch.max / torch.min propagate NaN
-    a.part_a[unit] = nan ? 0x7fc00000u : __builtin_bit_cast(uint32_t, mx);
-    a.part_b[unit] = nan ? 0x7fc00000u : __builtin_bit_cast(uint32_t, mn);
+    a.part_a[u.id] = nan ? 0x7fc00000u : __builtin_bit_cast(uint32_t, mx);
+    a.part_b[u.id] = nan ? 0x7fc00000u : __builtin_bit_cast(uint32_t, mn);
   }
 }
 
@@ -131,18 +124,31 @@ __device__ __forceinline__ void store_stat(void* out, int out_dtype, int64_t idx
     reinterpret_cast<f16_t*>(out)[idx] = (f16_t)v;
 }
 
+// optional epilogue of the abs-max finisher: statistic -> scale in the same launch
+//   thr   = scalar_clamp_min_ste(stat, min_val)      (B/core/restrict_val.py:22-42)
+//   scale = thr / int_threshold                       (B/core/quant/int.py:160)
+// min_val is already rounded to the statistic's dtype and int_threshold to the dtype the division
+// runs in, so the kernel only has to round the quotient to scale_dtype.
+struct ScaleEpilogue {
+  void* scale_out;  // null: no epilogue
+  int32_t scale_dtype;
+  int32_t use_min;
+  float min_val;
+  float int_threshold;
+};
+
 // one workgroup per channel; combines the per-unit partials of that channel
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void stat_finish_kernel(const uint32_t* __restrict__ part_a,
                                                              const uint32_t* __restrict__ part_b,
                                                              void* out, int out_dtype, int in_dtype,
-                                                             int64_t outer, int32_t channels,
-                                                             int64_t ppr) {
+                                                             int64_t nob, int32_t channels,
+                                                             int64_t ppr, ScaleEpilogue ep) {
   __shared__ uint32_t sha[kBlock];
   __shared__ float shx[kBlock], shn[kBlock];
   __shared__ uint32_t shnan[kBlock];
   const int32_t c = blockIdx.x;
-  const int64_t n = outer * ppr;
+  const int64_t n = nob * ppr;  // units of this channel: (outer_block * channels + c) * ppr + piece
   uint32_t m = 0;
   float mx = -__builtin_inff(), mn = __builtin_inff();
   uint32_t nan = 0;
@@ -184,12 +190,39 @@ __global__ __launch_bounds__(kBlock) void stat_finish_kernel(const uint32_t* __r
         v = __builtin_bit_cast(float, sha[0]);
       }
       store_stat(out, out_dtype, c, v);
+      if (ep.scale_out) {
+        const float thr = (ep.use_min && v < ep.min_val) ? ep.min_val : v;  // NaN passes, like torch.clamp_min
+        store_stat(ep.scale_out, ep.scale_dtype, c, thr / ep.int_threshold);
+      }
     } else {
       const float qn = __builtin_nanf("");
       store_stat(out, out_dtype, c, shnan[0] ? qn : shx[0]);
       store_stat(out, out_dtype, (int64_t)channels + c, shnan[0] ? qn : shn[0]);
     }
   }
+}
+
+// Running average of a statistic, as _RuntimeStats keeps it (B/core/stats/stats_wrapper.py:61-66):
+//   first batch:  running *= out
+//   afterwards :  running *= (1 - momentum) ; running += momentum * out
+// every torch op rounds to its result dtype: running's for the in-place ops, out's for momentum * out.
+__global__ void running_stats_kernel(void* running, int run_dtype, const void* stat, int stat_dtype,
+                                     int64_t n, float one_minus_m, float m, int first) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r = load_scalar_as_f(running, run_dtype, i);
+  const float o = load_scalar_as_f(stat, stat_dtype, i);
+  auto round_to = [](float v, int dt) {
+    return dt == BVQ_F32 ? v : (dt == BVQ_BF16 ? rnd<bf16_t>(v) : rnd<f16_t>(v));
+  };
+  if (first) {
+    r = round_to(r * o, run_dtype);
+  } else {
+    r = round_to(r * one_minus_m, run_dtype);
+    const float u = round_to(o * m, stat_dtype);
+    r = round_to(r + u, run_dtype);
+  }
+  store_stat(running, run_dtype, i, r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -220,43 +253,38 @@ __device__ __forceinline__ T zero_like(T v) {
 
 template <typename T, int VEC, int MATCH, bool WRITE_ZERO>
 __global__ __launch_bounds__(kBlock) void tie_scan_kernel(Tiling t, const void* x, const void* stat,
-                                                          unsigned long long* info, void* dx,
-                                                          int64_t inner) {
-  int64_t unit, start, len, row_off;
-  int32_t channel;
-  if (!locate(t, unit, start, len, channel, row_off)) return;
+                                                          unsigned long long* info, void* dx) {
+  const Unit u = locate_unit(t);
+  if (!u.valid) return;
   const int lane = threadIdx.x & 63;
-  const T* __restrict__ xp = reinterpret_cast<const T*>(x) + start;
-  T* __restrict__ dp = reinterpret_cast<T*>(dx) + start;
-  const T sv = reinterpret_cast<const T*>(stat)[channel];
+  const T* __restrict__ xp = reinterpret_cast<const T*>(x) + u.base;
+  T* __restrict__ dp = reinterpret_cast<T*>(dx) + u.base;
+  const T sv = reinterpret_cast<const T*>(stat)[u.channel];
   const bool per_channel = t.channels > 1;
-  // position of this unit's first element in the reference's reduction order for its channel:
-  // (outer index) * inner + offset inside the row
-  const int64_t row = unit / t.ppr;
-  const int64_t pos0 = per_channel ? (row / t.channels) * inner + row_off : start;
-  const int64_t nvec = len / VEC;
-  for (int64_t base = 0; base < nvec + 1; base += kWave) {
-    const int64_t i = base + lane;
-    const int64_t e0 = i * VEC;
-    if (i < nvec) {
-      const vec_t<T, VEC> xv = load_vec<T, VEC>(xp + e0);
+  ChunkCursor cur;
+  cur.init(u, VEC, lane);
+  const int64_t total = (int64_t)u.nrows * cur.cpr;
+  for (int64_t done = 0; done < total; done += kWave) {
+    if (cur.valid()) {
+      const int64_t off = cur.offset(u.row_stride, VEC);
+      const int64_t pos = u.pos0 + cur.pos(t.row_len, VEC);
+      const vec_t<T, VEC> xv = load_vec<T, VEC>(xp + off);
       vec_t<T, VEC> zv;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         zv.v[k] = zero_like<T, MATCH>(xv.v[k]);
-        if (is_tie<T, MATCH>(xv.v[k], sv)) {
-          record_tie(info, per_channel, channel, (unsigned long long)(pos0 + e0 + k));
-        }
+        if (is_tie<T, MATCH>(xv.v[k], sv))
+          record_tie(info, per_channel, u.channel, (unsigned long long)(pos + k));
       }
-      if (WRITE_ZERO) store_vec<T, VEC>(dp + e0, zv);
-    } else if (i == nvec) {
-      // ragged end: lane `nvec` walks the (< VEC) leftover elements
-      for (int64_t e = nvec * VEC; e < len; ++e) {
-        if (WRITE_ZERO) dp[e] = zero_like<T, MATCH>(xp[e]);
-        if (is_tie<T, MATCH>(xp[e], sv)) {
-          record_tie(info, per_channel, channel, (unsigned long long)(pos0 + e));
-        }
-      }
+      if (WRITE_ZERO) store_vec<T, VEC>(dp + off, zv);
+    }
+    cur.next();
+  }
+  // ragged end (single-row units only): lane 0 walks the (< VEC) leftover elements
+  if (u.nrows == 1 && lane == 0) {
+    for (int64_t e = (int64_t)cur.cpr * VEC; e < u.len; ++e) {
+      if (WRITE_ZERO) dp[e] = zero_like<T, MATCH>(xp[e]);
+      if (is_tie<T, MATCH>(xp[e], sv)) record_tie(info, per_channel, u.channel, (unsigned long long)(u.pos0 + e));
     }
   }
 }
@@ -347,77 +375,66 @@ __global__ __launch_bounds__(kBlock) void tie_apply_full_kernel(const void* x, c
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static Tiling stat_tiling(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
-                          int& vec) {
-  int64_t rows, row_len;
-  if (channels > 1) {
-    rows = outer * channels;
-    row_len = inner;
-  } else {
-    rows = 1;
-    row_len = outer * inner;
-  }
+static Tiling stat_tiling(int dtype, const void* x, const void* dx, int64_t outer, int64_t channels,
+                          int64_t inner, int& vec) {
+  // per-tensor: one row holding everything
+  const int64_t t_outer = channels > 1 ? outer : 1;
+  const int64_t row_len = channels > 1 ? inner : outer * inner;
   const int full = 16 / dtype_size(dtype);
-  const void* ptrs[1] = {x};
-  const int els[1] = {dtype_size(dtype)};
-  vec = pick_vec(full, rows, row_len, ptrs, els, 1);
-  vec = vec == full ? full : (vec >= 2 && full > 2 ? 2 : 1);
-  return make_tiling(rows, row_len, (int32_t)channels, vec);
+  const void* ptrs[2] = {x, dx};
+  const int els[2] = {dtype_size(dtype), dtype_size(dtype)};
+  vec = pick_vec(full, t_outer * channels, row_len, ptrs, els, 2);
+  vec = vec == full ? full : 1;
+  return make_tiling(t_outer, (int32_t)channels, row_len, vec);
 }
 
 static int64_t worst_units(int dtype, int64_t outer, int64_t channels, int64_t inner) {
-  int64_t rows = channels > 1 ? outer * channels : 1;
-  int64_t row_len = channels > 1 ? inner : outer * inner;
-  int64_t worst = 0;
-  for (int v = 1; v <= 16 / dtype_size(dtype); v <<= 1) {
-    Tiling t = make_tiling(rows, row_len, (int32_t)channels, v);
-    if (t.units > worst) worst = t.units;
-  }
-  return worst;
+  const int64_t t_outer = channels > 1 ? outer : 1;
+  const int64_t row_len = channels > 1 ? inner : outer * inner;
+  const int64_t a = make_tiling(t_outer, (int32_t)channels, row_len, 16 / dtype_size(dtype)).units;
+  const int64_t b = make_tiling(t_outer, (int32_t)channels, row_len, 1).units;
+  return a > b ? a : b;
 }
 
 template <typename T>
-static void launch_stat(int kind, const StatArgs& a, int vec, hipStream_t st) {
+static void launch_stat(int kind, const StatArgs& a, int vec, bool nt, hipStream_t st) {
   constexpr int V = elem<T>::vec;
   const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
   if (kind == BVQ_STAT_ABSMAX) {
-    if (vec == V)
-      absmax_kernel<T, V><<<grid, block, 0, st>>>(a);
-    else if (vec == 2)
-      absmax_kernel<T, 2><<<grid, block, 0, st>>>(a);
+    if (vec == V && nt)
+      absmax_kernel<T, V, true><<<grid, block, 0, st>>>(a);
+    else if (vec == V)
+      absmax_kernel<T, V, false><<<grid, block, 0, st>>>(a);
     else
-      absmax_kernel<T, 1><<<grid, block, 0, st>>>(a);
+      absmax_kernel<T, 1, false><<<grid, block, 0, st>>>(a);
   } else {
-    if (vec == V)
-      minmax_kernel<T, V><<<grid, block, 0, st>>>(a);
-    else if (vec == 2)
-      minmax_kernel<T, 2><<<grid, block, 0, st>>>(a);
+    if (vec == V && nt)
+      minmax_kernel<T, V, true><<<grid, block, 0, st>>>(a);
+    else if (vec == V)
+      minmax_kernel<T, V, false><<<grid, block, 0, st>>>(a);
     else
-      minmax_kernel<T, 1><<<grid, block, 0, st>>>(a);
+      minmax_kernel<T, 1, false><<<grid, block, 0, st>>>(a);
   }
 }
 
 template <typename T, int MATCH, bool WZ>
 static void launch_tie_scan_v(const Tiling& t, int vec, const void* x, const void* stat,
-                              unsigned long long* info, void* dx, int64_t inner, hipStream_t st) {
+                              unsigned long long* info, void* dx, hipStream_t st) {
   constexpr int V = elem<T>::vec;
   const dim3 grid(grid_for_units(t.units)), block(kBlock);
   if (vec == V)
-    tie_scan_kernel<T, V, MATCH, WZ><<<grid, block, 0, st>>>(t, x, stat, info, dx, inner);
-  else if (vec == 2)
-    tie_scan_kernel<T, 2, MATCH, WZ><<<grid, block, 0, st>>>(t, x, stat, info, dx, inner);
+    tie_scan_kernel<T, V, MATCH, WZ><<<grid, block, 0, st>>>(t, x, stat, info, dx);
   else
-    tie_scan_kernel<T, 1, MATCH, WZ><<<grid, block, 0, st>>>(t, x, stat, info, dx, inner);
+    tie_scan_kernel<T, 1, MATCH, WZ><<<grid, block, 0, st>>>(t, x, stat, info, dx);
 }
 
 template <typename T, int MATCH>
 static void run_tie_scan(const Tiling& t, int vec, const void* x, const void* stat,
-                         unsigned long long* info, void* dx, int64_t inner, int write_zeros,
-                         hipStream_t st) {
+                         unsigned long long* info, void* dx, int write_zeros, hipStream_t st) {
   if (write_zeros)
-    launch_tie_scan_v<T, MATCH, true>(t, vec, x, stat, info, dx, inner, st);
+    launch_tie_scan_v<T, MATCH, true>(t, vec, x, stat, info, dx, st);
   else
-    launch_tie_scan_v<T, MATCH, false>(t, vec, x, stat, info, dx, inner, st);
+    launch_tie_scan_v<T, MATCH, false>(t, vec, x, stat, info, dx, st);
 }
 
 template <typename T, int MATCH>
@@ -445,6 +462,28 @@ using namespace bvq;
 
 static int bad_dtype(int dt) { return dt < BVQ_F32 || dt > BVQ_F16; }
 
+// host-side float -> dtype -> float rounding (python scalars that torch converts to the tensor dtype)
+static float round_host(float f, int dt) {
+  if (dt == BVQ_F32 || f != f) return f;
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if (dt == BVQ_BF16) {
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return f;
+  }
+  const float a = fabsf(f);
+  if (a == 0.f) return f;
+  if (a >= 65520.f) return copysignf(INFINITY, f);
+  int e;
+  frexpf(a, &e);
+  int qexp = e - 11;
+  if (qexp < -24) qexp = -24;
+  const float q = ldexpf(1.f, qexp);
+  return copysignf(nearbyintf(a / q) * q, f);
+}
+
 extern "C" int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer, int64_t channels,
                                              int64_t inner) {
   if (bad_dtype(dtype) || outer < 0 || channels < 1 || inner < 0) return -1;
@@ -455,9 +494,9 @@ extern "C" int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer,
   return partials + tie + 256;
 }
 
-extern "C" int bvq_stats(int kind, int dtype, const void* x, int64_t outer, int64_t channels,
-                         int64_t inner, int out_dtype, void* out, void* workspace,
-                         int64_t workspace_bytes, bvq_stream_t stream) {
+static int stats_impl(int kind, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+                      int out_dtype, void* out, const ScaleEpilogue& ep, void* workspace,
+                      int64_t workspace_bytes, bvq_stream_t stream) {
   if (bad_dtype(dtype) || bad_dtype(out_dtype) || outer < 0 || channels < 1 || inner < 0 ||
       (kind != BVQ_STAT_ABSMAX && kind != BVQ_STAT_MINMAX)) {
     set_error("bvq_stats: bad argument");
@@ -478,7 +517,7 @@ extern "C" int bvq_stats(int kind, int dtype, const void* x, int64_t outer, int6
   }
   int vec;
   StatArgs a;
-  a.t = stat_tiling(dtype, x, outer, channels, inner, vec);
+  a.t = stat_tiling(dtype, x, nullptr, outer, channels, inner, vec);
   const int64_t need = 2 * a.t.units * (int64_t)sizeof(uint32_t);
   if (workspace_bytes < need) {
     set_error("bvq_stats: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
@@ -488,22 +527,66 @@ extern "C" int bvq_stats(int kind, int dtype, const void* x, int64_t outer, int6
   a.part_a = reinterpret_cast<uint32_t*>(workspace);
   a.part_b = a.part_a + a.t.units;
   hipStream_t st = (hipStream_t)stream;
+  const bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
   if (dtype == BVQ_F32)
-    launch_stat<float>(kind, a, vec, st);
+    launch_stat<float>(kind, a, vec, nt, st);
   else if (dtype == BVQ_BF16)
-    launch_stat<bf16_t>(kind, a, vec, st);
+    launch_stat<bf16_t>(kind, a, vec, nt, st);
   else
-    launch_stat<f16_t>(kind, a, vec, st);
+    launch_stat<f16_t>(kind, a, vec, nt, st);
   int rc = check_launch("bvq_stats");
   if (rc) return rc;
-  const int64_t outer_rows = channels > 1 ? outer : 1;
   if (kind == BVQ_STAT_ABSMAX)
     stat_finish_kernel<BVQ_STAT_ABSMAX><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(
-        a.part_a, a.part_b, out, out_dtype, dtype, outer_rows, (int32_t)channels, a.t.ppr);
+        a.part_a, a.part_b, out, out_dtype, dtype, a.t.nob, (int32_t)channels, a.t.ppr, ep);
   else
     stat_finish_kernel<BVQ_STAT_MINMAX><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(
-        a.part_a, a.part_b, out, out_dtype, dtype, outer_rows, (int32_t)channels, a.t.ppr);
+        a.part_a, a.part_b, out, out_dtype, dtype, a.t.nob, (int32_t)channels, a.t.ppr, ep);
   return check_launch("bvq_stats/finish");
+}
+
+extern "C" int bvq_stats(int kind, int dtype, const void* x, int64_t outer, int64_t channels,
+                         int64_t inner, int out_dtype, void* out, void* workspace,
+                         int64_t workspace_bytes, bvq_stream_t stream) {
+  ScaleEpilogue ep = {};
+  return stats_impl(kind, dtype, x, outer, channels, inner, out_dtype, out, ep, workspace, workspace_bytes,
+                    stream);
+}
+
+extern "C" int bvq_absmax_scale(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+                                void* stat_out, double min_val, int use_min, double int_threshold,
+                                int scale_dtype, void* scale_out, void* workspace,
+                                int64_t workspace_bytes, bvq_stream_t stream) {
+  if (bad_dtype(scale_dtype) || !scale_out || !(int_threshold == int_threshold)) {
+    set_error("bvq_absmax_scale: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  ScaleEpilogue ep;
+  ep.scale_out = scale_out;
+  ep.scale_dtype = scale_dtype;
+  ep.use_min = use_min;
+  ep.min_val = round_host((float)min_val, dtype);  // python scalar -> the statistic's dtype
+  ep.int_threshold = (float)int_threshold;
+  return stats_impl(BVQ_STAT_ABSMAX, dtype, x, outer, channels, inner, dtype, stat_out, ep, workspace,
+                    workspace_bytes, stream);
+}
+
+extern "C" int bvq_running_stats_update(int run_dtype, void* running, int stat_dtype, const void* stat,
+                                        int64_t n, double momentum, int first_batch,
+                                        bvq_stream_t stream) {
+  if (bad_dtype(run_dtype) || bad_dtype(stat_dtype) || n < 0) {
+    set_error("bvq_running_stats_update: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  if (n == 0) return BVQ_OK;
+  if (!running || !stat) {
+    set_error("bvq_running_stats_update: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  // torch turns the python scalars (1 - momentum) and momentum into float32 for these dtypes
+  running_stats_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      running, run_dtype, stat, stat_dtype, n, (float)(1.0 - momentum), (float)momentum, first_batch);
+  return check_launch("bvq_running_stats_update");
 }
 
 #define BVQ_DISPATCH_T_MATCH(dtype, match, FN, ...)              \
@@ -559,12 +642,8 @@ extern "C" int bvq_stat_tie_scan(int match, int dtype, const void* x, const void
     return BVQ_ERR_INVALID;
   }
   int vec;
-  Tiling t = stat_tiling(dtype, x, outer, channels, inner, vec);
-  if (dx_zero_fill && reinterpret_cast<uintptr_t>(dx_zero_fill) % 16 != 0 && vec > 1) {
-    vec = 1;
-    t = make_tiling(t.rows, t.row_len, t.channels, 1);
-  }
-  BVQ_DISPATCH_T_MATCH(dtype, match, run_tie_scan, t, vec, x, stat, info, dx_zero_fill, inner,
+  const Tiling t = stat_tiling(dtype, x, dx_zero_fill, outer, channels, inner, vec);
+  BVQ_DISPATCH_T_MATCH(dtype, match, run_tie_scan, t, vec, x, stat, info, dx_zero_fill,
                        dx_zero_fill != nullptr, st);
   return check_launch("bvq_stat_tie_scan");
 }

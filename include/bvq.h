@@ -162,6 +162,23 @@ int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer, int64_t ch
 int bvq_stats(int kind, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
               int out_dtype, void* out, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
 
+/* bvq_stats(ABSMAX) with the scale derivation of a stats-scaled quantizer in the same launches:
+ *   stat_out[c]  = max |x|                                        (dtype of x)
+ *   thr          = use_min ? clamp_min(stat, min_val) : stat      (scalar_clamp_min_ste, B/core/restrict_val.py:22-42;
+ *                                                                  min_val is rounded to the dtype of x like torch does)
+ *   scale_out[c] = thr / int_threshold, rounded to scale_dtype    (RescalingIntQuant.forward, B/core/quant/int.py:160)
+ * int_threshold is the value the division sees (the caller applies torch's promotion of the 0-dim
+ * int_threshold tensor); scale_dtype is the dtype torch gives the quotient. */
+int bvq_absmax_scale(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+                     void* stat_out, double min_val, int use_min, double int_threshold, int scale_dtype,
+                     void* scale_out, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
+
+/* Running average kept by _RuntimeStats (B/core/stats/stats_wrapper.py:61-66), one launch:
+ *   first_batch: running *= stat ; otherwise running *= (1 - momentum); running += momentum * stat
+ * with torch's rounding points (in-place results in run_dtype, momentum * stat in stat_dtype). */
+int bvq_running_stats_update(int run_dtype, void* running, int stat_dtype, const void* stat, int64_t n,
+                             double momentum, int first_batch, bvq_stream_t stream);
+
 /* which elements attain the statistic */
 typedef enum bvq_match_kind {
   BVQ_MATCH_ABS = 0,  /* |x| == stat, deposit scaled by sgn(x): torch.max(torch.abs(x)) (AbsMax)   */

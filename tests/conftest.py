@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # Build the CPU oracle NOW, before any test initialises the GPU: building runs `make` in a child
+    # process, and a process that has touched the GPU must not spawn/exec other programs on the box.
+    import oracle as orc
+    orc.build()
 
 
 @pytest.fixture(scope='session')

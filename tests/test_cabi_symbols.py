@@ -1,0 +1,61 @@
+"""The C-ABI library loads on a machine without a GPU and exports every function include/bvq.h
+declares (no compute calls here); descriptor layout and argument checking are host-side."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, 'include', 'bvq.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(bvq_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    assert 'bvq_fakequant_fwd' in names and 'bvq_fakequant_bwd' in names and 'bvq_stats' in names
+    assert len(names) >= 16
+
+
+def test_library_exports_every_declared_symbol():
+    from brevitas_amd import _native
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(_native.EXPORTS) == declared_functions()
+
+
+def test_abi_version_and_error_channel():
+    from brevitas_amd import _native as nat
+    assert nat.lib.bvq_abi_version() == nat.ABI_VERSION == 1
+    # argument validation happens before anything touches a device
+    rc = nat.lib.bvq_unary(99, nat.F32, None, None, 4, None)
+    assert rc < 0 and nat.last_error()
+    rc = nat.lib.bvq_fakequant_fwd(None, None, None, None, None, None, None)
+    assert rc == -1 and 'descriptor' in nat.last_error()
+    d = nat.QuantDesc(1, 1, 16, nat.F32, nat.BF16, nat.F32, nat.F32, 0, 0, -128.0, 127.0, 0, 0, 0, 0)
+    assert nat.lib.bvq_fakequant_fwd(ctypes.byref(d), None, None, None, None, None, None) == -2  # f32 x cannot compute in bf16
+    d = nat.QuantDesc(1, 1, 16, nat.F32, nat.F32, nat.F32, nat.F32, 0, 0, -128.0, 127.0, 7, 0, 0, 0)
+    assert nat.lib.bvq_fakequant_fwd(ctypes.byref(d), None, None, None, None, None, None) == -1  # bad round mode
+    assert nat.lib.bvq_stats_workspace_bytes(0, nat.BF16, 256, 512, 3136) > 0
+    assert nat.lib.bvq_tie_info_bytes(512) == 512 * 8
+    assert nat.lib.bvq_tie_info_bytes(0) == -1
+
+
+def test_descriptor_layout_matches_header():
+    """bvq_quant_desc: three int64 then twelve 4-byte fields, no padding surprises"""
+    from brevitas_amd import _native as nat
+    assert ctypes.sizeof(nat.QuantDesc) == 3 * 8 + 12 * 4
+    assert nat.QuantDesc.qmin.offset == 3 * 8 + 6 * 4
+
+
+def test_missing_library_is_an_import_error(tmp_path, monkeypatch):
+    """the product fails loudly when the HIP extension is absent"""
+    from brevitas_amd import _native
+    monkeypatch.setattr(_native, 'LIB_PATH', str(tmp_path / 'libbvq.so'))
+    with pytest.raises(ImportError, match='no fallback'):
+        _native._load()
