@@ -30,7 +30,7 @@ _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 EXPORTS = (
     'bvq_abi_version', 'bvq_last_error', 'bvq_unary', 'bvq_scalar_clamp', 'bvq_tensor_clamp',
     'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
-    'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
+    'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
 
 
 class QuantDesc(ctypes.Structure):
@@ -74,6 +74,7 @@ def _load(path=None):
         'bvq_tie_info_bytes': (i64, [i64]),
         'bvq_stat_tie_scan': (i32, [i32, i32, vp, vp, i64, i64, i64, vp, vp, vp]),
         'bvq_stat_tie_apply': (i32, [i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
+        'bvq_stat_tie_apply_dscale': (i32, [i32, vp, vp, vp, i32, dbl, i32, vp, vp, vp, i64, i64, i64, vp]),
         'bvq_fakequant_bwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     }
     for name, (res, args) in sig.items():
@@ -319,6 +320,20 @@ def stat_tie_apply(match, x, stat, gstat, info, dx, outer, channels, inner, mode
         check(lib.bvq_stat_tie_apply(match, dtype_code(x.dtype), ptr(x), ptr(stat), ptr(gstat), ptr(info),
                                      ptr(total_ties), ptr(dx), outer, channels, inner, int(mode_add),
                                      stream_ptr(dev)), 'bvq_stat_tie_apply')
+    return dx
+
+
+def stat_tie_apply_dscale(x, stat, dscale, scale_dtype, int_threshold, quot_dtype, info, dx, outer, channels,
+                          inner, total_ties=None):
+    """deposit the statistic's gradient derived from float32 dscale sums (fused quantizer backward)"""
+    dev = require_device(x, stat, dscale, info, dx, total_ties)
+    assert x.is_contiguous() and dx.is_contiguous() and dx.dtype == x.dtype and dscale.dtype == torch.float32
+    stat = stat.to(x.dtype).contiguous()
+    with torch.cuda.device(dev):
+        check(lib.bvq_stat_tie_apply_dscale(dtype_code(x.dtype), ptr(x), ptr(stat), ptr(dscale),
+                                            dtype_code(scale_dtype), float(int_threshold), dtype_code(quot_dtype),
+                                            ptr(info), ptr(total_ties), ptr(dx), outer, channels, inner,
+                                            stream_ptr(dev)), 'bvq_stat_tie_apply_dscale')
     return dx
 
 

@@ -158,6 +158,7 @@ class StatsFakeQuantFn(Function):
 
     @staticmethod
     def forward(ctx, x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, group=None):
+        ctx.set_materialize_grads(False)  # an unused `scale` output must not cost a zero-fill + add
         xc = x.contiguous()
         flat = xc.reshape(-1)
         if group is None:
@@ -201,11 +202,23 @@ class StatsFakeQuantFn(Function):
         xc, scale, zp, stat, int_threshold = ctx.saved_tensors
         desc, sp = ctx.desc, ctx.sp
         ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
+        if gy is None:  # only `scale` was used downstream
+            if gscale is None:
+                return None, None, None, None, None, None, None, None
+            gy = torch.zeros(xc.shape, dtype=ct, device=xc.device)
         gy = gy.to(ct).contiguous()
         # one pass: dx, the scale-gradient sums and the positions attaining the statistic
         dx, ds, _, ties = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), True,
                                             False, tie_stat=stat)
         total_ties = None
+        if ctx.group is None and gscale is None and ds.numel() == scale.numel():
+            # dscale -> dstat -> deposit in one launch (same rounding points as the ops below)
+            dimensioned = scale.dim() > 0
+            quot_dtype = scale.dtype if dimensioned else torch.promote_types(scale.dtype, int_threshold.dtype)
+            thr_div = _as_dtype_value(sp.int_threshold, scale.dtype) if dimensioned else sp.int_threshold
+            nat.stat_tie_apply_dscale(xc.reshape(-1), stat, ds, scale.dtype, thr_div, quot_dtype, ties,
+                                      dx.reshape(-1), sp.outer, sp.channels, sp.inner)
+            return dx, None, None, None, None, None, None, None
         if ctx.group is not None:
             # sum the shards' partial sums, and agree on which shard deposits the statistic's gradient
             from brevitas_amd.distributed import sync_backward

@@ -302,6 +302,30 @@ void launch_tie_init(unsigned long long* info, int64_t channels, hipStream_t st)
   tie_init_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, st>>>(info, (int32_t)channels);
 }
 
+// Where the statistic's gradient comes from: an array of the statistic's dtype, or the float32
+// scale-gradient sums of the fused quantizer backward, taken through
+//   dscale.to(scale dtype)  ->  / int_threshold (in the dtype torch computes that quotient in)  ->  .to(T)
+// i.e. the backward of  scale = clamp_min_ste(stat) / int_threshold  (B/core/quant/int.py:160).
+struct GstatSrc {
+  const void* p;
+  int32_t from_dscale;  // 0: p holds T values; 1: p holds float32 dscale sums
+  int32_t scale_dtype;
+  int32_t quot_dtype;
+  float int_threshold;
+};
+
+__device__ __forceinline__ float round_rt(float v, int dt) {
+  return dt == BVQ_F32 ? v : (dt == BVQ_BF16 ? rnd<bf16_t>(v) : rnd<f16_t>(v));
+}
+
+template <typename T>
+__device__ __forceinline__ float gstat_value(const GstatSrc& g, int64_t c) {
+  if (!g.from_dscale) return to_f<T>(reinterpret_cast<const T*>(g.p)[c]);
+  float v = round_rt(reinterpret_cast<const float*>(g.p)[c], g.scale_dtype);
+  v = round_rt(v / g.int_threshold, g.quot_dtype);
+  return rnd<T>(v);
+}
+
 template <typename T, int MATCH>
 __device__ __forceinline__ float deposit(float g, T xv) {
   if constexpr (MATCH == BVQ_MATCH_ABS) {
@@ -313,7 +337,7 @@ __device__ __forceinline__ float deposit(float g, T xv) {
 
 // channels > 1: one thread per channel deposits the gradient at first[c]
 template <typename T, int MATCH>
-__global__ void tie_apply_first_kernel(const void* x, const void* gstat, const unsigned long long* info,
+__global__ void tie_apply_first_kernel(const void* x, GstatSrc gstat, const unsigned long long* info,
                                        void* dx, int64_t outer, int32_t channels, int64_t inner,
                                        int mode_add) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -325,13 +349,13 @@ __global__ void tie_apply_first_kernel(const void* x, const void* gstat, const u
   const int64_t flat = (o * channels + c) * inner + i;
   const T* xp = reinterpret_cast<const T*>(x);
   T* dp = reinterpret_cast<T*>(dx);
-  const float term = deposit<T, MATCH>(to_f<T>(reinterpret_cast<const T*>(gstat)[c]), xp[flat]);
+  const float term = deposit<T, MATCH>(gstat_value<T>(gstat, c), xp[flat]);
   dp[flat] = mode_add ? from_f<T>(to_f<T>(dp[flat]) + term) : from_f<T>(term);
 }
 
 // channels == 1, ties fit the list: each tie receives (gstat / count)
 template <typename T, int MATCH>
-__global__ void tie_apply_list_kernel(const void* x, const void* gstat, const unsigned long long* info,
+__global__ void tie_apply_list_kernel(const void* x, GstatSrc gstat, const unsigned long long* info,
                                       const unsigned long long* total, void* dx, int mode_add) {
   const unsigned long long local = info[0];
   if (local == 0 || local > (unsigned long long)kTieCap) return;
@@ -340,7 +364,7 @@ __global__ void tie_apply_list_kernel(const void* x, const void* gstat, const un
   T* dp = reinterpret_cast<T*>(dx);
   // grad / mask.sum(): the count is an integer tensor, the quotient has the gradient's dtype
   // (the integer count is converted to the gradient's dtype first, as torch's type promotion does)
-  const float share = rnd<T>(to_f<T>(reinterpret_cast<const T*>(gstat)[0]) / rnd<T>((float)cnt));
+  const float share = rnd<T>(gstat_value<T>(gstat, 0) / rnd<T>((float)cnt));
   for (unsigned long long k = blockIdx.x * blockDim.x + threadIdx.x; k < local;
        k += (unsigned long long)gridDim.x * blockDim.x) {
     const int64_t flat = (int64_t)info[2 + k];
@@ -352,7 +376,7 @@ __global__ void tie_apply_list_kernel(const void* x, const void* gstat, const un
 // channels == 1, more ties than the list holds (constant tensors, binarised weights): full pass
 template <typename T, int MATCH>
 __global__ __launch_bounds__(kBlock) void tie_apply_full_kernel(const void* x, const void* stat,
-                                                                const void* gstat,
+                                                                GstatSrc gstat,
                                                                 const unsigned long long* info,
                                                                 const unsigned long long* total,
                                                                 void* dx, int64_t n, int mode_add) {
@@ -362,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void tie_apply_full_kernel(const void* x, c
   const T* xp = reinterpret_cast<const T*>(x);
   T* dp = reinterpret_cast<T*>(dx);
   const T sv = reinterpret_cast<const T*>(stat)[0];
-  const float share = rnd<T>(to_f<T>(reinterpret_cast<const T*>(gstat)[0]) / rnd<T>((float)cnt));
+  const float share = rnd<T>(gstat_value<T>(gstat, 0) / rnd<T>((float)cnt));
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const T xv = xp[i];
     if (is_tie<T, MATCH>(xv, sv)) {
@@ -438,7 +462,7 @@ static void run_tie_scan(const Tiling& t, int vec, const void* x, const void* st
 }
 
 template <typename T, int MATCH>
-static void run_tie_apply(const void* x, const void* stat, const void* gstat,
+static void run_tie_apply(const void* x, const void* stat, GstatSrc gstat,
                           const unsigned long long* info, const unsigned long long* total, void* dx,
                           int64_t outer, int64_t channels, int64_t inner, int mode_add, hipStream_t st) {
   if (channels > 1) {
@@ -660,11 +684,43 @@ extern "C" int bvq_stat_tie_apply(int match, int dtype, const void* x, const voi
     return BVQ_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
-  BVQ_DISPATCH_T_MATCH(dtype, match, run_tie_apply, x, stat, gstat,
+  GstatSrc src = {};
+  src.p = gstat;
+  BVQ_DISPATCH_T_MATCH(dtype, match, run_tie_apply, x, stat, src,
                        reinterpret_cast<const unsigned long long*>(tie_info),
                        reinterpret_cast<const unsigned long long*>(total_ties), dx, outer, channels, inner,
                        mode_add, st);
   return check_launch("bvq_stat_tie_apply");
+}
+
+extern "C" int bvq_stat_tie_apply_dscale(int dtype, const void* x, const void* stat, const float* dscale,
+                                         int scale_dtype, double int_threshold, int quot_dtype,
+                                         const int64_t* tie_info, const int64_t* total_ties, void* dx,
+                                         int64_t outer, int64_t channels, int64_t inner,
+                                         bvq_stream_t stream) {
+  int rc = check_stat_args("bvq_stat_tie_apply_dscale", BVQ_MATCH_ABS, dtype, outer, channels, inner);
+  if (rc) return rc;
+  if (bad_dtype(scale_dtype) || bad_dtype(quot_dtype)) {
+    set_error("bvq_stat_tie_apply_dscale: bad dtype");
+    return BVQ_ERR_INVALID;
+  }
+  if (outer * channels * inner == 0) return BVQ_OK;
+  if (!x || !stat || !dscale || !tie_info || !dx) {
+    set_error("bvq_stat_tie_apply_dscale: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  GstatSrc src;
+  src.p = dscale;
+  src.from_dscale = 1;
+  src.scale_dtype = scale_dtype;
+  src.quot_dtype = quot_dtype;
+  src.int_threshold = (float)int_threshold;
+  BVQ_DISPATCH_T_MATCH(dtype, BVQ_MATCH_ABS, run_tie_apply, x, stat, src,
+                       reinterpret_cast<const unsigned long long*>(tie_info),
+                       reinterpret_cast<const unsigned long long*>(total_ties), dx, outer, channels, inner, 1,
+                       st);
+  return check_launch("bvq_stat_tie_apply_dscale");
 }
 
 extern "C" int bvq_stat_bwd(int match, int dtype, const void* x, const void* stat, const void* gstat,

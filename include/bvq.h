@@ -217,6 +217,16 @@ int bvq_stat_tie_apply(int match, int dtype, const void* x, const void* stat, co
                        const int64_t* tie_info, const int64_t* total_ties, void* dx, int64_t outer,
                        int64_t channels, int64_t inner, int mode_add, bvq_stream_t stream);
 
+/* bvq_stat_tie_apply(MATCH_ABS, mode_add = 1) for the fused stats-scaled quantizer, taking the
+ * float32 scale-gradient sums of bvq_fakequant_bwd directly: per channel the deposited gradient is
+ *   ((dscale.to(scale_dtype)) / int_threshold -> quot_dtype).to(dtype of x)
+ * i.e. the backward of  scale = clamp_min_ste(stat) / int_threshold  (B/core/quant/int.py:160,
+ * B/core/restrict_val.py:22-42) with torch's rounding points, without the three tiny launches. */
+int bvq_stat_tie_apply_dscale(int dtype, const void* x, const void* stat, const float* dscale,
+                              int scale_dtype, double int_threshold, int quot_dtype,
+                              const int64_t* tie_info, const int64_t* total_ties, void* dx, int64_t outer,
+                              int64_t channels, int64_t inner, bvq_stream_t stream);
+
 /* ---- fused affine quantize / dequantize (seam 2: IntQuant) ---------------------------------- */
 
 /* Forward: one read of x, one write of y.
