@@ -23,12 +23,13 @@ STAT_ABSMAX, STAT_MINMAX = 0, 1
 SCALAR_OPMATH, SCALAR_CAST = 0, 1
 OUT_DEQUANT, OUT_INT = 0, 1
 MATCH_ABS, MATCH_VALUE = 0, 1
+PRE_NONE, PRE_RELU = 0, 1
 ABI_VERSION = 1
 
 _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 EXPORTS = (
-    'bvq_abi_version', 'bvq_last_error', 'bvq_unary', 'bvq_scalar_clamp', 'bvq_tensor_clamp',
+    'bvq_abi_version', 'bvq_last_error', 'bvq_unary', 'bvq_stats_pre', 'bvq_scalar_clamp', 'bvq_tensor_clamp',
     'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
     'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
 
@@ -41,7 +42,7 @@ class QuantDesc(ctypes.Structure):
         ('zp_dtype', ctypes.c_int32), ('scale_per_channel', ctypes.c_int32),
         ('zp_per_channel', ctypes.c_int32), ('qmin', ctypes.c_float), ('qmax', ctypes.c_float),
         ('round_mode', ctypes.c_int32), ('scalar_mode', ctypes.c_int32), ('clamp_ste', ctypes.c_int32),
-        ('out_kind', ctypes.c_int32)]
+        ('out_kind', ctypes.c_int32), ('pre_op', ctypes.c_int32)]
 
 
 class BvqError(RuntimeError):
@@ -66,15 +67,16 @@ def _load(path=None):
         'bvq_abs_binary_sign_grad_bwd': (i32, [i32, vp, vp, vp, i64, vp]),
         'bvq_stats_workspace_bytes': (i64, [i32, i32, i64, i64, i64]),
         'bvq_stats': (i32, [i32, i32, vp, i64, i64, i64, i32, vp, vp, i64, vp]),
+        'bvq_stats_pre': (i32, [i32, i32, i32, vp, i64, i64, i64, i32, vp, vp, i64, vp]),
         'bvq_stat_bwd': (i32, [i32, i32, vp, vp, vp, vp, i64, i64, i64, i32, vp, i64, vp]),
         'bvq_fakequant_fwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp]),
         'bvq_fakequant_bwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
-        'bvq_absmax_scale': (i32, [i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
+        'bvq_absmax_scale': (i32, [i32, i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
         'bvq_running_stats_update': (i32, [i32, vp, i32, vp, i64, dbl, i32, vp]),
         'bvq_tie_info_bytes': (i64, [i64]),
         'bvq_stat_tie_scan': (i32, [i32, i32, vp, vp, i64, i64, i64, vp, vp, vp]),
-        'bvq_stat_tie_apply': (i32, [i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
-        'bvq_stat_tie_apply_dscale': (i32, [i32, vp, vp, vp, i32, dbl, i32, vp, vp, vp, i64, i64, i64, vp]),
+        'bvq_stat_tie_apply': (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
+        'bvq_stat_tie_apply_dscale': (i32, [i32, i32, vp, vp, vp, i32, dbl, i32, vp, vp, vp, i64, i64, i64, vp]),
         'bvq_fakequant_bwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     }
     for name, (res, args) in sig.items():
@@ -207,7 +209,7 @@ def abs_binary_sign_grad_bwd(g, x):
     return dx
 
 
-def stats(kind, x, outer, channels, inner, out_f32=False):
+def stats(kind, x, outer, channels, inner, out_f32=False, pre_op=PRE_NONE):
     """x contiguous, viewed as [outer, channels, inner] -> [channels] (ABSMAX) or [2, channels]"""
     dev = require_device(x)
     assert x.is_contiguous() and x.numel() == outer * channels * inner
@@ -221,8 +223,8 @@ def stats(kind, x, outer, channels, inner, out_f32=False):
     with torch.cuda.device(dev):
         if _timer is not None:
             _timer.before('bvq_stats')
-        check(lib.bvq_stats(kind, dt, ptr(x), outer, channels, inner, dtype_code(out.dtype), ptr(out), ptr(ws),
-                            ws.numel(), stream_ptr(dev)), 'bvq_stats')
+        check(lib.bvq_stats_pre(kind, pre_op, dt, ptr(x), outer, channels, inner, dtype_code(out.dtype), ptr(out),
+                                ptr(ws), ws.numel(), stream_ptr(dev)), 'bvq_stats')
         if _timer is not None:
             _timer.after('bvq_stats')
     return out
@@ -262,7 +264,7 @@ def fakequant_fwd(desc, x, scale, zp, want_codes=False):
     return (y, codes) if want_codes else y
 
 
-def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype):
+def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype, pre_op=PRE_NONE):
     """abs-max statistic and the scale derived from it, one call: -> (stat [channels], scale [channels])"""
     dev = require_device(x)
     assert x.is_contiguous() and x.numel() == outer * channels * inner
@@ -274,7 +276,7 @@ def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype)
     with torch.cuda.device(dev):
         if _timer is not None:
             _timer.before('bvq_stats')
-        check(lib.bvq_absmax_scale(dt, ptr(x), outer, channels, inner, ptr(stat), float(min_val or 0.0),
+        check(lib.bvq_absmax_scale(pre_op, dt, ptr(x), outer, channels, inner, ptr(stat), float(min_val or 0.0),
                                    int(bool(min_val)), float(int_threshold), dtype_code(scale_dtype), ptr(scale),
                                    ptr(ws), ws.numel(), stream_ptr(dev)), 'bvq_absmax_scale')
         if _timer is not None:
@@ -311,26 +313,27 @@ def stat_tie_scan(match, x, stat, outer, channels, inner, dx_zero_fill=None):
     return info
 
 
-def stat_tie_apply(match, x, stat, gstat, info, dx, outer, channels, inner, mode_add, total_ties=None):
+def stat_tie_apply(match, x, stat, gstat, info, dx, outer, channels, inner, mode_add, total_ties=None,
+                   pre_op=PRE_NONE):
     dev = require_device(x, stat, gstat, info, dx, total_ties)
     assert x.is_contiguous() and dx.is_contiguous() and dx.dtype == x.dtype
     stat = stat.to(x.dtype).contiguous()
     gstat = gstat.to(x.dtype).contiguous()
     with torch.cuda.device(dev):
-        check(lib.bvq_stat_tie_apply(match, dtype_code(x.dtype), ptr(x), ptr(stat), ptr(gstat), ptr(info),
+        check(lib.bvq_stat_tie_apply(match, pre_op, dtype_code(x.dtype), ptr(x), ptr(stat), ptr(gstat), ptr(info),
                                      ptr(total_ties), ptr(dx), outer, channels, inner, int(mode_add),
                                      stream_ptr(dev)), 'bvq_stat_tie_apply')
     return dx
 
 
 def stat_tie_apply_dscale(x, stat, dscale, scale_dtype, int_threshold, quot_dtype, info, dx, outer, channels,
-                          inner, total_ties=None):
+                          inner, total_ties=None, pre_op=PRE_NONE):
     """deposit the statistic's gradient derived from float32 dscale sums (fused quantizer backward)"""
     dev = require_device(x, stat, dscale, info, dx, total_ties)
     assert x.is_contiguous() and dx.is_contiguous() and dx.dtype == x.dtype and dscale.dtype == torch.float32
     stat = stat.to(x.dtype).contiguous()
     with torch.cuda.device(dev):
-        check(lib.bvq_stat_tie_apply_dscale(dtype_code(x.dtype), ptr(x), ptr(stat), ptr(dscale),
+        check(lib.bvq_stat_tie_apply_dscale(pre_op, dtype_code(x.dtype), ptr(x), ptr(stat), ptr(dscale),
                                             dtype_code(scale_dtype), float(int_threshold), dtype_code(quot_dtype),
                                             ptr(info), ptr(total_ties), ptr(dx), outer, channels, inner,
                                             stream_ptr(dev)), 'bvq_stat_tie_apply_dscale')

@@ -1,3 +1,3 @@
 from .delay import DelayWrapper
-from .int import RescalingIntQuant
+from .int import PrescaledRestrictIntQuant, PrescaledRestrictIntQuantWithInputBitWidth, RescalingIntQuant
 from .int_base import IntQuant

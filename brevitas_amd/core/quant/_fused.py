@@ -77,10 +77,11 @@ def scalar_mode():
     return nat.SCALAR_CAST if config.SCALAR_OPERAND_MODE == 'device' else nat.SCALAR_OPMATH
 
 
-def make_desc(p: Plan, x: Tensor, scale: Tensor, zp: Tensor, qmin, qmax, round_mode, clamp_ste, out_kind):
+def make_desc(p: Plan, x: Tensor, scale: Tensor, zp: Tensor, qmin, qmax, round_mode, clamp_ste, out_kind,
+              pre_op=nat.PRE_NONE):
     return nat.QuantDesc(p.outer, p.channels, p.inner, nat.dtype_code(x.dtype), nat.dtype_code(p.ct),
                          nat.dtype_code(scale.dtype), nat.dtype_code(zp.dtype), int(p.scale_pc), int(p.zp_pc),
-                         qmin, qmax, round_mode, scalar_mode(), int(clamp_ste), out_kind)
+                         qmin, qmax, round_mode, scalar_mode(), int(clamp_ste), out_kind, pre_op)
 
 
 def _reduce_like(sums: Tensor, like: Tensor) -> Tensor:
@@ -94,11 +95,11 @@ class FakeQuantFn(Function):
     """IntQuant.forward / IntQuant.to_int on the fused kernel (B/core/quant/int_base.py:63-97)"""
 
     @staticmethod
-    def forward(ctx, x, scale, zp, p, qmin, qmax, round_mode, clamp_ste, out_kind):
+    def forward(ctx, x, scale, zp, p, qmin, qmax, round_mode, clamp_ste, out_kind, pre_op=nat.PRE_NONE):
         xc = x.contiguous()
         sc = scale.reshape(-1).contiguous()
         zc = zp.reshape(-1).contiguous()
-        desc = make_desc(p, xc, sc, zc, qmin, qmax, round_mode, clamp_ste, out_kind)
+        desc = make_desc(p, xc, sc, zc, qmin, qmax, round_mode, clamp_ste, out_kind, pre_op)
         y = nat.fakequant_fwd(desc, xc, sc, zc)
         ctx.desc = desc
         ctx.save_for_backward(xc, scale, zp)
@@ -117,7 +118,7 @@ class FakeQuantFn(Function):
                                        need_ds, need_dz)
         ds = _reduce_like(ds, scale) if need_ds else None
         dz = _reduce_like(dz, zp) if need_dz else None
-        return dx, ds, dz, None, None, None, None, None, None
+        return dx, ds, dz, None, None, None, None, None, None, None
 
 
 class StatsPlan(NamedTuple):
@@ -157,8 +158,9 @@ class StatsFakeQuantFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, group=None):
+    def forward(ctx, x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, group=None, pre_op=nat.PRE_NONE):
         ctx.set_materialize_grads(False)  # an unused `scale` output must not cost a zero-fill + add
+        ctx.pre_op = pre_op
         xc = x.contiguous()
         flat = xc.reshape(-1)
         if group is None:
@@ -170,12 +172,13 @@ class StatsFakeQuantFn(Function):
             else:
                 scale_dtype = torch.promote_types(x.dtype, int_threshold.dtype)
                 thr_div = sp.int_threshold
-            stat, scale = nat.absmax_scale(flat, sp.outer, sp.channels, sp.inner, sp.min_val, thr_div, scale_dtype)
+            stat, scale = nat.absmax_scale(flat, sp.outer, sp.channels, sp.inner, sp.min_val, thr_div, scale_dtype,
+                                           pre_op)
             scale = scale.view(sp.scaling_shape)
         else:
             # batch-sharded tensor: the statistic of the whole batch is the max over the shards
             from brevitas_amd.distributed import sync_stat_max
-            stat32 = nat.stats(nat.STAT_ABSMAX, flat, sp.outer, sp.channels, sp.inner, out_f32=True)
+            stat32 = nat.stats(nat.STAT_ABSMAX, flat, sp.outer, sp.channels, sp.inner, out_f32=True, pre_op=pre_op)
             stat = sync_stat_max(stat32, group).to(x.dtype)
             # _StatsScaling with float restriction: scalar_clamp_min_ste (B/core/restrict_val.py:22-42)
             thr = nat.scalar_clamp(stat, sp.min_val, None) if sp.min_val else stat
@@ -187,7 +190,7 @@ class StatsFakeQuantFn(Function):
         if p is None:
             raise nat.BvqError('StatsFakeQuantFn: unsupported operand layout (caller must pre-check)')
         sc = scale.reshape(-1).contiguous()
-        desc = make_desc(p, xc, sc, zp.reshape(-1), qmin, qmax, round_mode, clamp_ste, nat.OUT_DEQUANT)
+        desc = make_desc(p, xc, sc, zp.reshape(-1), qmin, qmax, round_mode, clamp_ste, nat.OUT_DEQUANT, pre_op)
         y = nat.fakequant_fwd(desc, xc, sc, zp.reshape(-1))
         ctx.desc = desc
         ctx.sp = sp
@@ -204,7 +207,7 @@ class StatsFakeQuantFn(Function):
         ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
         if gy is None:  # only `scale` was used downstream
             if gscale is None:
-                return None, None, None, None, None, None, None, None
+                return None, None, None, None, None, None, None, None, None
             gy = torch.zeros(xc.shape, dtype=ct, device=xc.device)
         gy = gy.to(ct).contiguous()
         # one pass: dx, the scale-gradient sums and the positions attaining the statistic
@@ -217,8 +220,8 @@ class StatsFakeQuantFn(Function):
             quot_dtype = scale.dtype if dimensioned else torch.promote_types(scale.dtype, int_threshold.dtype)
             thr_div = _as_dtype_value(sp.int_threshold, scale.dtype) if dimensioned else sp.int_threshold
             nat.stat_tie_apply_dscale(xc.reshape(-1), stat, ds, scale.dtype, thr_div, quot_dtype, ties,
-                                      dx.reshape(-1), sp.outer, sp.channels, sp.inner)
-            return dx, None, None, None, None, None, None, None
+                                      dx.reshape(-1), sp.outer, sp.channels, sp.inner, pre_op=ctx.pre_op)
+            return dx, None, None, None, None, None, None, None, None
         if ctx.group is not None:
             # sum the shards' partial sums, and agree on which shard deposits the statistic's gradient
             from brevitas_amd.distributed import sync_backward
@@ -232,5 +235,5 @@ class StatsFakeQuantFn(Function):
         # scale = thr / int_threshold  ->  dthr = dscale / int_threshold ; clamp_min_ste passes it on
         dstat = (ds / int_threshold).to(stat.dtype).reshape(-1).contiguous()
         nat.stat_tie_apply(nat.MATCH_ABS, xc.reshape(-1), stat, dstat, ties, dx.reshape(-1), sp.outer,
-                           sp.channels, sp.inner, mode_add=True, total_ties=total_ties)
-        return dx, None, None, None, None, None, None, None
+                           sp.channels, sp.inner, mode_add=True, total_ties=total_ties, pre_op=ctx.pre_op)
+        return dx, None, None, None, None, None, None, None, None

@@ -24,7 +24,9 @@ from brevitas_amd.core.quant import _fused
 from brevitas_amd.core.quant.delay import _NoDelay
 from brevitas_amd.core.quant.int_base import IntQuant
 from brevitas_amd.core.scaling.int_scaling import IntScaling
+from brevitas_amd import _native as nat
 from brevitas_amd.core.scaling.runtime import RuntimeStatsScaling, StatsFromParameterScaling
+from brevitas_amd.core.scaling.standalone import ConstScaling, ParameterFromRuntimeStatsScaling, ParameterScaling
 from brevitas_amd.core.stats.stats_op import AbsMax
 from brevitas_amd.core.zero_point import ZeroZeroPoint
 from brevitas_amd.function.ops import int_range_host
@@ -111,8 +113,36 @@ class RescalingIntQuant(torch.nn.Module):
         return None
 
     def forward(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+        return self.bvq_forward_pre(x, nat.PRE_NONE)
+
+    def _scale_ignores_input(self) -> bool:
+        """True if scaling_impl(x) does not read x right now (learned / constant / frozen statistics)"""
+        sc = self.scaling_impl
+        if type(sc) in (ParameterScaling, ConstScaling):
+            return True
+        if type(sc) is RuntimeStatsScaling:
+            return not sc.training
+        if type(sc) is ParameterFromRuntimeStatsScaling:
+            return (not sc.training) or sc.counter >= sc.collect_stats_steps
+        return False
+
+    def bvq_forward_pre(self, x: Tensor, pre_op: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+        """forward(pre_op(x)) -- FusedActivationQuantProxy.forward (B/proxy/runtime_quant.py:80-84) -- with
+        the activation folded into the statistic / quantizer kernels wherever those kernels apply, so
+        the activation's own read + write (and its backward pass) disappear."""
         bit_width = self.msb_clamp_bit_width_impl()
         fused = self._stats_plan(x, bit_width)
+        if fused is None and pre_op != nat.PRE_NONE:
+            if type(self.int_quant) is IntQuant and type(self.zero_point_impl) is ZeroZeroPoint \
+                    and self._scale_ignores_input():
+                threshold = self.scaling_impl(x)
+                int_threshold = self.int_scaling_impl(bit_width)
+                scale = threshold / int_threshold
+                zero_point = self.zero_point_impl(x, scale, bit_width)
+                y = self.int_quant.bvq_forward_pre(scale, zero_point, bit_width, x, pre_op)
+                return y, scale, zero_point, bit_width
+            x = torch.relu(x)  # not fusable here: materialise the activation like the reference does
+            pre_op = nat.PRE_NONE
         if fused is not None:
             sp, runtime = fused
             iq = self.int_quant
@@ -122,7 +152,7 @@ class RescalingIntQuant(torch.nn.Module):
             group = getattr(self, 'bvq_shard_group', None) if runtime is not None else None
             y, scale, stat = _fused.StatsFakeQuantFn.apply(
                 x, int_threshold, sp, qmin, qmax, iq.float_to_int_impl.bvq_round_mode,
-                iq.tensor_clamp_impl.bvq_clamp_ste, group)
+                iq.tensor_clamp_impl.bvq_clamp_ste, group, pre_op)
             if runtime is not None:
                 runtime.update_running_stats(stat)
             zero_point = self.zero_point_impl(x, scale, bit_width)
@@ -134,3 +164,46 @@ class RescalingIntQuant(torch.nn.Module):
         zero_point = self.zero_point_impl(x, scale, bit_width)
         y = self.int_quant(scale, zero_point, bit_width, x)
         return y, scale, zero_point, bit_width
+
+
+class PrescaledRestrictIntQuantWithInputBitWidth(torch.nn.Module):
+    """IntQuant with an externally supplied scale, zero zero-point, and a bit width derived from the
+    input's (drop-in for B/core/quant/int.py:17-69; bias quantization with scale = input * weight scale).
+
+    Examples (B/core/quant/int.py:32-48):
+        >>> q = PrescaledRestrictIntQuantWithInputBitWidth(IntQuant(narrow_range=True, signed=True), Identity())
+        >>> out, scale, zero_point, bit_width = q(inp, torch.tensor(0.01), torch.tensor(4.))
+        >>> out
+        tensor([ 0.0400, -0.0500,  0.0700, -0.0700])
+    """
+
+    def __init__(self, int_quant: Module, bit_width_impl: Module):
+        super().__init__()
+        from brevitas_amd.core.utils import StatelessBuffer
+        self.int_quant = int_quant
+        self.msb_clamp_bit_width_impl = bit_width_impl
+        self.zero_point = StatelessBuffer(torch.tensor(0.0))
+
+    def forward(self, x: Tensor, scale: Tensor, input_bit_width: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+        bit_width = self.msb_clamp_bit_width_impl(input_bit_width)
+        zero_point = self.zero_point()
+        y = self.int_quant(scale, zero_point, bit_width, x)
+        return y, scale, zero_point, bit_width
+
+
+class PrescaledRestrictIntQuant(torch.nn.Module):
+    """IntQuant with an externally supplied scale, zero zero-point and its own bit width
+    (drop-in for B/core/quant/int.py:72-91)"""
+
+    def __init__(self, int_quant: Module, bit_width_impl: Module):
+        super().__init__()
+        from brevitas_amd.core.utils import StatelessBuffer
+        self.int_quant = int_quant
+        self.msb_clamp_bit_width_impl = bit_width_impl
+        self.zero_point = StatelessBuffer(torch.tensor(0.0))
+
+    def forward(self, x: Tensor, scale: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+        msb_clamp_bit_width = self.msb_clamp_bit_width_impl()
+        zero_point = self.zero_point()
+        y = self.int_quant(scale, zero_point, msb_clamp_bit_width, x)
+        return y, scale, zero_point, msb_clamp_bit_width

@@ -14,7 +14,7 @@ import brevitas_amd.config as config
 from brevitas_amd import _native as nat
 from brevitas_amd.core.function_wrapper import RoundSte, TensorClamp
 from brevitas_amd.core.quant import _fused
-from brevitas_amd.core.quant.delay import DelayWrapper
+from brevitas_amd.core.quant.delay import DelayWrapper, _NoDelay
 from brevitas_amd.function.ops import int_range_host, max_int, min_int
 
 
@@ -86,13 +86,23 @@ class IntQuant(torch.nn.Module):
         return max_int(self.signed, self.narrow_range, bit_width)
 
     def forward(self, scale: Tensor, zero_point: Tensor, bit_width: Tensor, x: Tensor) -> Tensor:
+        return self.bvq_forward_pre(scale, zero_point, bit_width, x, nat.PRE_NONE)
+
+    def bvq_forward_pre(self, scale: Tensor, zero_point: Tensor, bit_width: Tensor, x: Tensor, pre_op: int
+                        ) -> Tensor:
+        """forward(scale, zero_point, bit_width, pre_op(x)) with the activation `pre_op`
+        (include/bvq.h, bvq_pre_op) folded into the quantizer kernel when that kernel applies"""
         fa = self._fused_args(scale, zero_point, bit_width, x)
         if fa is not None and not bit_width.requires_grad:
             p, qmin, qmax, round_mode, clamp_ste = fa
             y = _fused.FakeQuantFn.apply(x, scale, zero_point, p, qmin, qmax, round_mode, clamp_ste,
-                                         nat.OUT_DEQUANT)
+                                         nat.OUT_DEQUANT, pre_op)
+            x_act = x  # only handed back while quantization is delayed; see below
+            if pre_op != nat.PRE_NONE and not isinstance(self.delay_wrapper.delay_impl, _NoDelay):
+                x_act = torch.relu(x)
         else:
-            y_int = self.to_int(scale, zero_point, bit_width, x)
+            x_act = torch.relu(x) if pre_op == nat.PRE_RELU else x
+            y_int = self.to_int(scale, zero_point, bit_width, x_act)
             y = y_int - zero_point
             y = y * scale
-        return self.delay_wrapper(x, y)
+        return self.delay_wrapper(x_act, y)

@@ -30,6 +30,7 @@ struct QuantArgs {
   int32_t clamp_ste;
   int32_t out_int;
   int32_t round_mode;
+  int32_t pre_relu;  // x is passed through torch.relu first (FusedActivationQuantProxy)
 };
 
 #ifndef BVQ_FWD_UNROLL
@@ -104,7 +105,7 @@ __device__ __forceinline__ float fwd_elem(float xf, const Div& div, float s, flo
   return ZP0 ? rnd<CT>(q * s) : rnd<CT>(rnd<CT>(q - z) * s);  // (y_int - zero_point) * scale :93-94
 }
 
-template <typename XT, typename CT, int VEC, int RM, bool NT, bool ZP0, typename Div>
+template <typename XT, typename CT, int VEC, int RM, bool NT, bool ZP0, bool PRE, typename Div>
 __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, const Div& div, float s,
                                          float z, float qmin, float qmax) {
   const int lane = threadIdx.x & 63;
@@ -135,8 +136,8 @@ __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, cons
         float qv[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          const float r =
-              fwd_elem<CT, RM, ZP0>(to_f<XT>(xv[j].v[k]), div, s, z, qmin, qmax, out_int, mode, qv[k]);
+          const float xf = PRE ? relu_f(to_f<XT>(xv[j].v[k])) : to_f<XT>(xv[j].v[k]);
+          const float r = fwd_elem<CT, RM, ZP0>(xf, div, s, z, qmin, qmax, out_int, mode, qv[k]);
           yv.v[k] = from_f<CT>(r);
         }
         store_vec<CT, VEC, NT>(yp + off[j], yv);
@@ -153,7 +154,8 @@ __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, cons
   const int64_t i = (int64_t)cur.cpr * VEC + lane;
   if (u.nrows == 1 && i < u.len) {
     float q;
-    const float r = fwd_elem<CT, RM, ZP0>(to_f<XT>(xp[i]), div, s, z, qmin, qmax, out_int, mode, q);
+    const float xf = PRE ? relu_f(to_f<XT>(xp[i])) : to_f<XT>(xp[i]);
+    const float r = fwd_elem<CT, RM, ZP0>(xf, div, s, z, qmin, qmax, out_int, mode, q);
     yp[i] = from_f<CT>(r);
     if (cp) cp[i] = (int32_t)q;
   }
@@ -167,13 +169,20 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
   load_scale_zp<CT>(a, u.channel, s, z);
   // the reference clamps against min_int/max_int converted to the tensor dtype (max_val.type_as(x))
   const float qmin = rnd<CT>(a.qmin), qmax = rnd<CT>(a.qmax);
+  // wave-uniform choices: fused pre-activation, and (bf16) the reciprocal fast path
   if constexpr (elem<CT>::id == BVQ_BF16) {
     if (bf16_fast_ok(s, z)) {
-      fwd_unit<XT, CT, VEC, RM, NT, true>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
+      if (a.pre_relu)
+        fwd_unit<XT, CT, VEC, RM, NT, true, true>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
+      else
+        fwd_unit<XT, CT, VEC, RM, NT, true, false>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
       return;
     }
   }
-  fwd_unit<XT, CT, VEC, RM, NT, false>(a, u, DivExact{s}, s, z, qmin, qmax);
+  if (a.pre_relu)
+    fwd_unit<XT, CT, VEC, RM, NT, false, true>(a, u, DivExact{s}, s, z, qmin, qmax);
+  else
+    fwd_unit<XT, CT, VEC, RM, NT, false, false>(a, u, DivExact{s}, s, z, qmin, qmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -213,7 +222,7 @@ __device__ __forceinline__ float bwd_elem(float xf, float gf, const Div& div, fl
   return dxv;
 }
 
-template <typename XT, typename CT, int VEC, int RM, int MODE, bool NT, bool ZP0, typename Div>
+template <typename XT, typename CT, int VEC, int RM, int MODE, bool NT, bool ZP0, bool PRE, typename Div>
 __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, const Div& div, float s,
                                          float z, float qmin, float qmax) {
   const int lane = threadIdx.x & 63;
@@ -258,13 +267,14 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
         uint32_t mx = 0;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          const float d =
-              bwd_elem<CT, RM, MODE, ZP0>(to_f<XT>(xv[j].v[k]), to_f<CT>(gv[j].v[k]), div, s, z, qmin,
-                                          qmax, clamp_ste, mode, ds_acc, dzp_acc);
+          const float xraw = to_f<XT>(xv[j].v[k]);
+          float d = bwd_elem<CT, RM, MODE, ZP0>(PRE ? relu_f(xraw) : xraw, to_f<CT>(gv[j].v[k]), div, s, z,
+                                                qmin, qmax, clamp_ste, mode, ds_acc, dzp_acc);
+          if constexpr (PRE) d = xraw > 0.f ? d : 0.f;  // torch.relu backward: grad * (x > 0)
           dv.v[k] = from_f<XT>(d);
           if constexpr (MODE == kBwdDsTies) {
             // cheap chunk-level filter: a tie in this chunk needs the chunk's max |x| to reach the statistic
-            const uint32_t b = abs_bits<XT>(xv[j].v[k]);
+            const uint32_t b = pre_abs_bits<XT, PRE>(xv[j].v[k]);
             mx = b > mx ? b : mx;
           }
         }
@@ -272,7 +282,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
         if constexpr (MODE == kBwdDsTies) {
           if (mx >= stat_bits) {  // rare: a handful of elements per channel attain the maximum
             for (int k = 0; k < VEC; ++k)
-              if (abs_bits<XT>(xv[j].v[k]) == stat_bits)
+              if (pre_abs_bits<XT, PRE>(xv[j].v[k]) == stat_bits)
                 record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(pos[j] + k));
           }
         }
@@ -281,11 +291,13 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
   }
   const int64_t i = (int64_t)cur.cpr * VEC + lane;
   if (u.nrows == 1 && i < u.len) {
-    const float d = bwd_elem<CT, RM, MODE, ZP0>(to_f<XT>(xp[i]), to_f<CT>(gp[i]), div, s, z, qmin, qmax,
-                                                clamp_ste, mode, ds_acc, dzp_acc);
+    const float xraw = to_f<XT>(xp[i]);
+    float d = bwd_elem<CT, RM, MODE, ZP0>(PRE ? relu_f(xraw) : xraw, to_f<CT>(gp[i]), div, s, z, qmin, qmax,
+                                          clamp_ste, mode, ds_acc, dzp_acc);
+    if constexpr (PRE) d = xraw > 0.f ? d : 0.f;
     dxp[i] = from_f<XT>(d);
     if constexpr (MODE == kBwdDsTies) {
-      if (abs_bits<XT>(xp[i]) == stat_bits)
+      if (pre_abs_bits<XT, PRE>(xp[i]) == stat_bits)
         record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(u.pos0 + i));
     }
   }
@@ -308,11 +320,17 @@ __global__ __launch_bounds__(kBlock) void fakequant_bwd_kernel(QuantArgs a) {
   const float qmin = rnd<CT>(a.qmin), qmax = rnd<CT>(a.qmax);
   if constexpr (elem<CT>::id == BVQ_BF16) {
     if (bf16_fast_ok(s, z)) {
-      bwd_unit<XT, CT, VEC, RM, MODE, NT, true>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
+      if (a.pre_relu)
+        bwd_unit<XT, CT, VEC, RM, MODE, NT, true, true>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
+      else
+        bwd_unit<XT, CT, VEC, RM, MODE, NT, true, false>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
       return;
     }
   }
-  bwd_unit<XT, CT, VEC, RM, MODE, NT, false>(a, u, DivExact{s}, s, z, qmin, qmax);
+  if (a.pre_relu)
+    bwd_unit<XT, CT, VEC, RM, MODE, NT, false, true>(a, u, DivExact{s}, s, z, qmin, qmax);
+  else
+    bwd_unit<XT, CT, VEC, RM, MODE, NT, false, false>(a, u, DivExact{s}, s, z, qmin, qmax);
 }
 
 // Combine per-unit partial sums of one channel in a fixed order (double accumulation):
@@ -361,6 +379,10 @@ static int validate(const bvq_quant_desc* d) {
               (long long)d->inner);
     return BVQ_ERR_INVALID;
   }
+  if (d->pre_op != BVQ_PRE_NONE && d->pre_op != BVQ_PRE_RELU) {
+    set_error("bad pre_op %d", d->pre_op);
+    return BVQ_ERR_INVALID;
+  }
   if (d->round_mode < BVQ_ROUND || d->round_mode > BVQ_DPU_ROUND) {
     set_error("bad round_mode %d", d->round_mode);
     return BVQ_ERR_INVALID;
@@ -404,6 +426,7 @@ static void fill_args(QuantArgs& a, const bvq_quant_desc* d) {
   a.clamp_ste = d->clamp_ste;
   a.out_int = d->out_kind == BVQ_OUT_INT;
   a.round_mode = d->round_mode;
+  a.pre_relu = d->pre_op == BVQ_PRE_RELU;
 }
 
 // instantiated vector widths: 16 bytes of x per lane, or one element (ragged / misaligned rows)

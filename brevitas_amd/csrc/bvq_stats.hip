@@ -25,7 +25,7 @@ struct StatArgs {
   uint32_t* part_b;  // MINMAX: min as float bits
 };
 
-template <typename T, int VEC, bool NT>
+template <typename T, int VEC, bool NT, bool RELU>
 __global__ __launch_bounds__(kBlock) void absmax_kernel(StatArgs a) {
   const Unit u = locate_unit(a.t);
   if (!u.valid) return;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void absmax_kernel(StatArgs a) {
       if (ok[j]) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          const uint32_t b = abs_bits<T>(xv[j].v[k]);
+          const uint32_t b = pre_abs_bits<T, RELU>(xv[j].v[k]);
           m = b > m ? b : m;
         }
       }
@@ -58,14 +58,14 @@ __global__ __launch_bounds__(kBlock) void absmax_kernel(StatArgs a) {
   // ragged end (single-row units only)
   const int64_t i = (int64_t)cur.cpr * VEC + lane;
   if (u.nrows == 1 && i < u.len) {
-    const uint32_t b = abs_bits<T>(xp[i]);
+    const uint32_t b = pre_abs_bits<T, RELU>(xp[i]);
     m = b > m ? b : m;
   }
   m = wave_max_u32(m);
   if (lane == 0) a.part_a[u.id] = m;
 }
 
-template <typename T, int VEC, bool NT>
+template <typename T, int VEC, bool NT, bool RELU>
 __global__ __launch_bounds__(kBlock) void minmax_kernel(StatArgs a) {
   const Unit u = locate_unit(a.t);
   if (!u.valid) return;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(StatArgs a) {
       if (ok[j]) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          const float f = to_f<T>(xv[j].v[k]);
+          const float f = RELU ? relu_f(to_f<T>(xv[j].v[k])) : to_f<T>(xv[j].v[k]);
           nan |= (f != f) ? 1u : 0u;
           mx = fmaxf(mx, f);
           mn = fminf(mn, f);
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(StatArgs a) {
   }
   const int64_t i = (int64_t)cur.cpr * VEC + lane;
   if (u.nrows == 1 && i < u.len) {
-    const float f = to_f<T>(xp[i]);
+    const float f = RELU ? relu_f(to_f<T>(xp[i])) : to_f<T>(xp[i]);
     nan |= (f != f) ? 1u : 0u;
     mx = fmaxf(mx, f);
     mn = fminf(mn, f);
@@ -312,6 +312,7 @@ struct GstatSrc {
   int32_t scale_dtype;
   int32_t quot_dtype;
   float int_threshold;
+  int32_t pre_relu;  // the statistic was taken of relu(x): the deposit's sign is sgn(relu(x))
 };
 
 __device__ __forceinline__ float round_rt(float v, int dt) {
@@ -327,9 +328,9 @@ __device__ __forceinline__ float gstat_value(const GstatSrc& g, int64_t c) {
 }
 
 template <typename T, int MATCH>
-__device__ __forceinline__ float deposit(float g, T xv) {
+__device__ __forceinline__ float deposit(float g, T xv, bool pre_relu = false) {
   if constexpr (MATCH == BVQ_MATCH_ABS) {
-    return rnd<T>(g * sgn_f(to_f<T>(xv)));
+    return rnd<T>(g * sgn_f(pre_relu ? relu_f(to_f<T>(xv)) : to_f<T>(xv)));
   } else {
     return g;
   }
@@ -349,7 +350,7 @@ __global__ void tie_apply_first_kernel(const void* x, GstatSrc gstat, const unsi
   const int64_t flat = (o * channels + c) * inner + i;
   const T* xp = reinterpret_cast<const T*>(x);
   T* dp = reinterpret_cast<T*>(dx);
-  const float term = deposit<T, MATCH>(gstat_value<T>(gstat, c), xp[flat]);
+  const float term = deposit<T, MATCH>(gstat_value<T>(gstat, c), xp[flat], gstat.pre_relu != 0);
   dp[flat] = mode_add ? from_f<T>(to_f<T>(dp[flat]) + term) : from_f<T>(term);
 }
 
@@ -368,7 +369,7 @@ __global__ void tie_apply_list_kernel(const void* x, GstatSrc gstat, const unsig
   for (unsigned long long k = blockIdx.x * blockDim.x + threadIdx.x; k < local;
        k += (unsigned long long)gridDim.x * blockDim.x) {
     const int64_t flat = (int64_t)info[2 + k];
-    const float term = deposit<T, MATCH>(share, xp[flat]);
+    const float term = deposit<T, MATCH>(share, xp[flat], gstat.pre_relu != 0);
     dp[flat] = mode_add ? from_f<T>(to_f<T>(dp[flat]) + term) : from_f<T>(term);
   }
 }
@@ -389,8 +390,11 @@ __global__ __launch_bounds__(kBlock) void tie_apply_full_kernel(const void* x, c
   const float share = rnd<T>(gstat_value<T>(gstat, 0) / rnd<T>((float)cnt));
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const T xv = xp[i];
-    if (is_tie<T, MATCH>(xv, sv)) {
-      const float term = deposit<T, MATCH>(share, xv);
+    const bool tie = (gstat.pre_relu && MATCH == BVQ_MATCH_ABS)
+                         ? pre_abs_bits<T, true>(xv) == abs_bits<T>(sv)
+                         : is_tie<T, MATCH>(xv, sv);
+    if (tie) {
+      const float term = deposit<T, MATCH>(share, xv, gstat.pre_relu != 0);
       dp[i] = mode_add ? from_f<T>(to_f<T>(dp[i]) + term) : from_f<T>(term);
     }
   }
@@ -420,25 +424,33 @@ static int64_t worst_units(int dtype, int64_t outer, int64_t channels, int64_t i
   return a > b ? a : b;
 }
 
-template <typename T>
-static void launch_stat(int kind, const StatArgs& a, int vec, bool nt, hipStream_t st) {
+template <typename T, bool RELU>
+static void launch_stat_pre(int kind, const StatArgs& a, int vec, bool nt, hipStream_t st) {
   constexpr int V = elem<T>::vec;
   const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
   if (kind == BVQ_STAT_ABSMAX) {
     if (vec == V && nt)
-      absmax_kernel<T, V, true><<<grid, block, 0, st>>>(a);
+      absmax_kernel<T, V, true, RELU><<<grid, block, 0, st>>>(a);
     else if (vec == V)
-      absmax_kernel<T, V, false><<<grid, block, 0, st>>>(a);
+      absmax_kernel<T, V, false, RELU><<<grid, block, 0, st>>>(a);
     else
-      absmax_kernel<T, 1, false><<<grid, block, 0, st>>>(a);
+      absmax_kernel<T, 1, false, RELU><<<grid, block, 0, st>>>(a);
   } else {
     if (vec == V && nt)
-      minmax_kernel<T, V, true><<<grid, block, 0, st>>>(a);
+      minmax_kernel<T, V, true, RELU><<<grid, block, 0, st>>>(a);
     else if (vec == V)
-      minmax_kernel<T, V, false><<<grid, block, 0, st>>>(a);
+      minmax_kernel<T, V, false, RELU><<<grid, block, 0, st>>>(a);
     else
-      minmax_kernel<T, 1, false><<<grid, block, 0, st>>>(a);
+      minmax_kernel<T, 1, false, RELU><<<grid, block, 0, st>>>(a);
   }
+}
+
+template <typename T>
+static void launch_stat(int kind, int pre_op, const StatArgs& a, int vec, bool nt, hipStream_t st) {
+  if (pre_op == BVQ_PRE_RELU)
+    launch_stat_pre<T, true>(kind, a, vec, nt, st);
+  else
+    launch_stat_pre<T, false>(kind, a, vec, nt, st);
 }
 
 template <typename T, int MATCH, bool WZ>
@@ -518,9 +530,13 @@ extern "C" int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer,
   return partials + tie + 256;
 }
 
-static int stats_impl(int kind, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
-                      int out_dtype, void* out, const ScaleEpilogue& ep, void* workspace,
+static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t outer, int64_t channels,
+                      int64_t inner, int out_dtype, void* out, const ScaleEpilogue& ep, void* workspace,
                       int64_t workspace_bytes, bvq_stream_t stream) {
+  if (pre_op != BVQ_PRE_NONE && pre_op != BVQ_PRE_RELU) {
+    set_error("bvq_stats: bad pre_op %d", pre_op);
+    return BVQ_ERR_INVALID;
+  }
   if (bad_dtype(dtype) || bad_dtype(out_dtype) || outer < 0 || channels < 1 || inner < 0 ||
       (kind != BVQ_STAT_ABSMAX && kind != BVQ_STAT_MINMAX)) {
     set_error("bvq_stats: bad argument");
@@ -553,11 +569,11 @@ static int stats_impl(int kind, int dtype, const void* x, int64_t outer, int64_t
   hipStream_t st = (hipStream_t)stream;
   const bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
   if (dtype == BVQ_F32)
-    launch_stat<float>(kind, a, vec, nt, st);
+    launch_stat<float>(kind, pre_op, a, vec, nt, st);
   else if (dtype == BVQ_BF16)
-    launch_stat<bf16_t>(kind, a, vec, nt, st);
+    launch_stat<bf16_t>(kind, pre_op, a, vec, nt, st);
   else
-    launch_stat<f16_t>(kind, a, vec, nt, st);
+    launch_stat<f16_t>(kind, pre_op, a, vec, nt, st);
   int rc = check_launch("bvq_stats");
   if (rc) return rc;
   if (kind == BVQ_STAT_ABSMAX)
@@ -573,11 +589,20 @@ extern "C" int bvq_stats(int kind, int dtype, const void* x, int64_t outer, int6
                          int64_t inner, int out_dtype, void* out, void* workspace,
                          int64_t workspace_bytes, bvq_stream_t stream) {
   ScaleEpilogue ep = {};
-  return stats_impl(kind, dtype, x, outer, channels, inner, out_dtype, out, ep, workspace, workspace_bytes,
-                    stream);
+  return stats_impl(kind, BVQ_PRE_NONE, dtype, x, outer, channels, inner, out_dtype, out, ep, workspace,
+                    workspace_bytes, stream);
 }
 
-extern "C" int bvq_absmax_scale(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+extern "C" int bvq_stats_pre(int kind, int pre_op, int dtype, const void* x, int64_t outer, int64_t channels,
+                             int64_t inner, int out_dtype, void* out, void* workspace,
+                             int64_t workspace_bytes, bvq_stream_t stream) {
+  ScaleEpilogue ep = {};
+  return stats_impl(kind, pre_op, dtype, x, outer, channels, inner, out_dtype, out, ep, workspace,
+                    workspace_bytes, stream);
+}
+
+extern "C" int bvq_absmax_scale(int pre_op, int dtype, const void* x, int64_t outer, int64_t channels,
+                                int64_t inner,
                                 void* stat_out, double min_val, int use_min, double int_threshold,
                                 int scale_dtype, void* scale_out, void* workspace,
                                 int64_t workspace_bytes, bvq_stream_t stream) {
@@ -591,7 +616,7 @@ extern "C" int bvq_absmax_scale(int dtype, const void* x, int64_t outer, int64_t
   ep.use_min = use_min;
   ep.min_val = round_host((float)min_val, dtype);  // python scalar -> the statistic's dtype
   ep.int_threshold = (float)int_threshold;
-  return stats_impl(BVQ_STAT_ABSMAX, dtype, x, outer, channels, inner, dtype, stat_out, ep, workspace,
+  return stats_impl(BVQ_STAT_ABSMAX, pre_op, dtype, x, outer, channels, inner, dtype, stat_out, ep, workspace,
                     workspace_bytes, stream);
 }
 
@@ -672,9 +697,9 @@ extern "C" int bvq_stat_tie_scan(int match, int dtype, const void* x, const void
   return check_launch("bvq_stat_tie_scan");
 }
 
-extern "C" int bvq_stat_tie_apply(int match, int dtype, const void* x, const void* stat, const void* gstat,
-                                  const int64_t* tie_info, const int64_t* total_ties, void* dx,
-                                  int64_t outer, int64_t channels, int64_t inner, int mode_add,
+extern "C" int bvq_stat_tie_apply(int match, int pre_op, int dtype, const void* x, const void* stat,
+                                  const void* gstat, const int64_t* tie_info, const int64_t* total_ties,
+                                  void* dx, int64_t outer, int64_t channels, int64_t inner, int mode_add,
                                   bvq_stream_t stream) {
   int rc = check_stat_args("bvq_stat_tie_apply", match, dtype, outer, channels, inner);
   if (rc) return rc;
@@ -686,6 +711,7 @@ extern "C" int bvq_stat_tie_apply(int match, int dtype, const void* x, const voi
   hipStream_t st = (hipStream_t)stream;
   GstatSrc src = {};
   src.p = gstat;
+  src.pre_relu = pre_op == BVQ_PRE_RELU;
   BVQ_DISPATCH_T_MATCH(dtype, match, run_tie_apply, x, stat, src,
                        reinterpret_cast<const unsigned long long*>(tie_info),
                        reinterpret_cast<const unsigned long long*>(total_ties), dx, outer, channels, inner,
@@ -693,7 +719,8 @@ extern "C" int bvq_stat_tie_apply(int match, int dtype, const void* x, const voi
   return check_launch("bvq_stat_tie_apply");
 }
 
-extern "C" int bvq_stat_tie_apply_dscale(int dtype, const void* x, const void* stat, const float* dscale,
+extern "C" int bvq_stat_tie_apply_dscale(int pre_op, int dtype, const void* x, const void* stat,
+                                         const float* dscale,
                                          int scale_dtype, double int_threshold, int quot_dtype,
                                          const int64_t* tie_info, const int64_t* total_ties, void* dx,
                                          int64_t outer, int64_t channels, int64_t inner,
@@ -710,12 +737,13 @@ extern "C" int bvq_stat_tie_apply_dscale(int dtype, const void* x, const void* s
     return BVQ_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
-  GstatSrc src;
+  GstatSrc src = {};
   src.p = dscale;
   src.from_dscale = 1;
   src.scale_dtype = scale_dtype;
   src.quot_dtype = quot_dtype;
   src.int_threshold = (float)int_threshold;
+  src.pre_relu = pre_op == BVQ_PRE_RELU;
   BVQ_DISPATCH_T_MATCH(dtype, BVQ_MATCH_ABS, run_tie_apply, x, stat, src,
                        reinterpret_cast<const unsigned long long*>(tie_info),
                        reinterpret_cast<const unsigned long long*>(total_ties), dx, outer, channels, inner, 1,
@@ -737,6 +765,6 @@ extern "C" int bvq_stat_bwd(int match, int dtype, const void* x, const void* sta
   rc = bvq_stat_tie_scan(match, dtype, x, stat, outer, channels, inner, mode_add ? nullptr : dx, info,
                          stream);
   if (rc) return rc;
-  return bvq_stat_tie_apply(match, dtype, x, stat, gstat, info, nullptr, dx, outer, channels, inner,
-                            mode_add, stream);
+  return bvq_stat_tie_apply(match, BVQ_PRE_NONE, dtype, x, stat, gstat, info, nullptr, dx, outer, channels,
+                            inner, mode_add, stream);
 }

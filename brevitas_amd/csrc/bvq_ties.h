@@ -41,6 +41,19 @@ __device__ __forceinline__ uint32_t abs_bits<f16_t>(f16_t v) {
   return (uint32_t)(__builtin_bit_cast(uint16_t, v) & 0x7fffu);
 }
 
+// torch.relu: x < 0 ? 0 : x  (NaN and -0.0 pass through unchanged)
+__device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
+
+// |pre_op(v)| as the same key: negative (non-NaN) values become 0 under RELU
+template <typename T, bool RELU>
+__device__ __forceinline__ uint32_t pre_abs_bits(T v) {
+  if constexpr (RELU) {
+    return to_f<T>(v) < 0.f ? 0u : abs_bits<T>(v);
+  } else {
+    return abs_bits<T>(v);
+  }
+}
+
 void launch_tie_init(unsigned long long* info, int64_t channels, hipStream_t st);
 
 }  // namespace bvq

@@ -1,0 +1,105 @@
+"""Resolved module graphs of the named quantizers on the accelerated path.
+
+In Brevitas these are injector classes (B/quant/scaled_int.py:144-193) that the solvers
+(B/quant/solver/*.py) resolve into a `tensor_quant` module graph; the injector machinery itself is
+out of scope, so the functions here assemble exactly the graphs the solvers produce
+(SURVEY 8a lists them with file:line) from brevitas_amd's same-named modules.  Each returns the
+`tensor_quant` a proxy would own: `q(x) -> (y, scale, zero_point, bit_width)`.
+"""
+from typing import List, Optional, Sequence, Union
+
+import torch
+
+from brevitas_amd.core.bit_width import BitWidthConst
+from brevitas_amd.core.function_wrapper import (OverOutputChannelView, OverTensorView, RoundSte, TensorClamp,
+                                                TensorClampSte)
+from brevitas_amd.core.quant import IntQuant, RescalingIntQuant
+from brevitas_amd.core.restrict_val import FloatRestrictValue
+from brevitas_amd.core.scaling import (IntScaling, ParameterFromRuntimeStatsScaling, ParameterScaling,
+                                       RuntimeStatsScaling, StatsFromParameterScaling)
+from brevitas_amd.core.stats import AbsMax
+from brevitas_amd.core.zero_point import ZeroZeroPoint
+
+__all__ = ['Int8WeightPerChannelFloat', 'Int4WeightPerChannelFloat', 'Int8WeightPerTensorFloat',
+           'Int8ActPerTensorFloat', 'Uint8ActPerTensorFloat', 'Int8ActPerChannelFloat']
+
+SCALING_MIN_VAL = 1e-10  # B/quant/base.py:115-123, 169-182
+
+
+def _params(weights) -> List[torch.nn.Parameter]:
+    return list(weights) if isinstance(weights, (list, tuple)) else [weights]
+
+
+def Int8WeightPerChannelFloat(weights: Union[torch.nn.Parameter, Sequence[torch.nn.Parameter]],
+                              bit_width: int = 8) -> RescalingIntQuant:
+    """NarrowIntQuant + MaxStatsScaling + PerChannelFloatScaling8bit + WeightQuantSolver
+    (B/quant/scaled_int.py:157-167): scale[c] = max(max_k |w[c,k]|, 1e-10) / (2^(b-1) - 1), narrow signed range,
+    straight-through clamp; weights are re-quantized on every forward."""
+    tracked = _params(weights)
+    w = tracked[0]
+    shape = (w.shape[0],) + (1,) * (w.dim() - 1)
+    return RescalingIntQuant(
+        IntQuant(narrow_range=True, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClampSte()),
+        StatsFromParameterScaling(AbsMax(1), OverOutputChannelView(None), 1, tracked, FloatRestrictValue(), shape,
+                                  affine_rescaling=False, scaling_min_val=SCALING_MIN_VAL),
+        IntScaling(signed=True, narrow_range=True), ZeroZeroPoint(), BitWidthConst(bit_width))
+
+
+def Int4WeightPerChannelFloat(weights) -> RescalingIntQuant:
+    """not in this reference snapshot; defined as Int8WeightPerChannelFloat with bit_width = 4"""
+    return Int8WeightPerChannelFloat(weights, bit_width=4)
+
+
+def Int8WeightPerTensorFloat(weights, bit_width: int = 8) -> RescalingIntQuant:
+    """B/quant/scaled_int.py:144-154: one scale for the whole weight tensor"""
+    tracked = _params(weights)
+    return RescalingIntQuant(
+        IntQuant(narrow_range=True, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClampSte()),
+        StatsFromParameterScaling(AbsMax(), OverTensorView(), 0, tracked, FloatRestrictValue(), (),
+                                  affine_rescaling=False, scaling_min_val=SCALING_MIN_VAL),
+        IntScaling(signed=True, narrow_range=True), ZeroZeroPoint(), BitWidthConst(bit_width))
+
+
+def _act_quant(signed: bool, bit_width: int, scaling_impl_type: str, collect_stats_steps: int,
+               channels: Optional[int], scaling_init: Optional[float]) -> RescalingIntQuant:
+    if channels is None:
+        view, stats, shape = OverTensorView(), AbsMax(), ()
+    else:
+        # scaling_per_output_channel=True, per_channel_broadcastable_shape=(1,C,1,1),
+        # scaling_stats_permute_dims=(1,0,2,3)  (B/quant/solver/act.py:91-105)
+        view, stats, shape = OverOutputChannelView((1, 0, 2, 3)), AbsMax(1), (1, channels, 1, 1)
+    if scaling_impl_type == 'parameter_from_stats':
+        scaling = ParameterFromRuntimeStatsScaling(collect_stats_steps, stats, view, shape, FloatRestrictValue(),
+                                                   0.1, SCALING_MIN_VAL)
+    elif scaling_impl_type == 'stats':
+        scaling = RuntimeStatsScaling(stats, view, FloatRestrictValue(), shape, affine_rescaling=False,
+                                      scaling_stats_momentum=0.1, scaling_min_val=SCALING_MIN_VAL)
+    elif scaling_impl_type == 'parameter':
+        scaling = ParameterScaling(scaling_init, shape if shape else None, FloatRestrictValue(), SCALING_MIN_VAL)
+    else:
+        raise ValueError("scaling_impl_type must be 'parameter_from_stats', 'stats' or 'parameter'")
+    return RescalingIntQuant(
+        IntQuant(narrow_range=False, signed=signed, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+        scaling, IntScaling(signed=signed, narrow_range=False), ZeroZeroPoint(), BitWidthConst(bit_width))
+
+
+def Int8ActPerTensorFloat(scaling_impl_type: str = 'parameter_from_stats', collect_stats_steps: int = 300,
+                          bit_width: int = 8, scaling_init: Optional[float] = None) -> RescalingIntQuant:
+    """IntQuant + ParamFromRuntime...Scaling + PerTensorFloatScaling8bit + ActQuantSolver
+    (B/quant/scaled_int.py:170-180) with the supported override scaling_stats_op = MAX (the reference's
+    default statistic, the 99.999th percentile, is a selection kernel and not on this path yet: SURVEY 8f).
+    Collects AbsMax for `collect_stats_steps` training steps, then learns the scale."""
+    return _act_quant(True, bit_width, scaling_impl_type, collect_stats_steps, None, scaling_init)
+
+
+def Uint8ActPerTensorFloat(scaling_impl_type: str = 'parameter_from_stats', collect_stats_steps: int = 300,
+                           bit_width: int = 8, scaling_init: Optional[float] = None) -> RescalingIntQuant:
+    """unsigned variant for post-ReLU activations (B/quant/scaled_int.py:183-193)"""
+    return _act_quant(False, bit_width, scaling_impl_type, collect_stats_steps, None, scaling_init)
+
+
+def Int8ActPerChannelFloat(channels: int, scaling_impl_type: str = 'stats', collect_stats_steps: int = 300,
+                           bit_width: int = 8) -> RescalingIntQuant:
+    """Int8ActPerTensorFloat with scaling_per_output_channel=True over NCHW channel `channels`
+    (the layout of BASELINE.json's metric)"""
+    return _act_quant(True, bit_width, scaling_impl_type, collect_stats_steps, channels, None)

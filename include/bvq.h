@@ -83,6 +83,12 @@ typedef enum bvq_stat_kind {
  * Same-dtype operands and per-channel operands are unaffected. */
 typedef enum bvq_scalar_mode { BVQ_SCALAR_OPMATH = 0, BVQ_SCALAR_CAST = 1 } bvq_scalar_mode;
 
+/* Elementwise activation applied to x BEFORE the statistic / the quantizer, fused into the same
+ * kernels: FusedActivationQuantProxy.forward = tensor_quant(activation_impl(x))
+ * (B/proxy/runtime_quant.py:73-84).  RELU: torch.relu forward (NaN and -0.0 pass), backward
+ * grad * (x > 0) (threshold_backward). */
+typedef enum bvq_pre_op { BVQ_PRE_NONE = 0, BVQ_PRE_RELU = 1 } bvq_pre_op;
+
 /* output selection for bvq_fakequant_fwd */
 #define BVQ_OUT_DEQUANT 0 /* y = (clamp(round(x/s+zp)) - zp) * s   IntQuant.forward, B/core/quant/int_base.py:86-97 */
 #define BVQ_OUT_INT 1     /* y =  clamp(round(x/s+zp))             IntQuant.to_int,  B/core/quant/int_base.py:63-76 */
@@ -111,6 +117,7 @@ typedef struct bvq_quant_desc {
   int32_t clamp_ste;   /* backward only. 1: TensorClampSte (grad passes clipped elements, weights);
                           0: TensorClamp (grad masked where clipped, activations). B/core/quant/int_base.py:53-54 */
   int32_t out_kind;    /* forward only. BVQ_OUT_DEQUANT or BVQ_OUT_INT */
+  int32_t pre_op;      /* bvq_pre_op applied to x first (forward and backward) */
 } bvq_quant_desc;
 
 /* ---- library ------------------------------------------------------------------------------ */
@@ -162,14 +169,20 @@ int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer, int64_t ch
 int bvq_stats(int kind, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
               int out_dtype, void* out, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
 
+/* the same statistic of pre_op(x) (bvq_pre_op), without materialising the activation */
+int bvq_stats_pre(int kind, int pre_op, int dtype, const void* x, int64_t outer, int64_t channels,
+                  int64_t inner, int out_dtype, void* out, void* workspace, int64_t workspace_bytes,
+                  bvq_stream_t stream);
+
 /* bvq_stats(ABSMAX) with the scale derivation of a stats-scaled quantizer in the same launches:
  *   stat_out[c]  = max |x|                                        (dtype of x)
  *   thr          = use_min ? clamp_min(stat, min_val) : stat      (scalar_clamp_min_ste, B/core/restrict_val.py:22-42;
  *                                                                  min_val is rounded to the dtype of x like torch does)
  *   scale_out[c] = thr / int_threshold, rounded to scale_dtype    (RescalingIntQuant.forward, B/core/quant/int.py:160)
  * int_threshold is the value the division sees (the caller applies torch's promotion of the 0-dim
- * int_threshold tensor); scale_dtype is the dtype torch gives the quotient. */
-int bvq_absmax_scale(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+ * int_threshold tensor); scale_dtype is the dtype torch gives the quotient.  pre_op: the statistic is
+ * taken of pre_op(x) (bvq_pre_op). */
+int bvq_absmax_scale(int pre_op, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
                      void* stat_out, double min_val, int use_min, double int_threshold, int scale_dtype,
                      void* scale_out, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
 
@@ -208,21 +221,23 @@ int bvq_stat_bwd(int match, int dtype, const void* x, const void* stat, const vo
  *   the zeros non-attaining elements receive (signed by sgn(x) for MATCH_ABS).
  * bvq_stat_tie_apply: deposits gstat at the recorded positions.  total_ties (nullable, device, one
  *   int64) replaces the local tie count when the ties of a whole-tensor maximum are spread over
- *   several shards. */
+ *   several shards.  pre_op (MATCH_ABS only): the statistic was taken of pre_op(x), so the deposit's
+ *   sign is sgn(pre_op(x)). */
 int64_t bvq_tie_info_bytes(int64_t channels);
 int bvq_stat_tie_scan(int match, int dtype, const void* x, const void* stat, int64_t outer,
                       int64_t channels, int64_t inner, void* dx_zero_fill, int64_t* tie_info,
                       bvq_stream_t stream);
-int bvq_stat_tie_apply(int match, int dtype, const void* x, const void* stat, const void* gstat,
-                       const int64_t* tie_info, const int64_t* total_ties, void* dx, int64_t outer,
-                       int64_t channels, int64_t inner, int mode_add, bvq_stream_t stream);
+int bvq_stat_tie_apply(int match, int pre_op, int dtype, const void* x, const void* stat,
+                       const void* gstat, const int64_t* tie_info, const int64_t* total_ties, void* dx,
+                       int64_t outer, int64_t channels, int64_t inner, int mode_add, bvq_stream_t stream);
 
 /* bvq_stat_tie_apply(MATCH_ABS, mode_add = 1) for the fused stats-scaled quantizer, taking the
  * float32 scale-gradient sums of bvq_fakequant_bwd directly: per channel the deposited gradient is
  *   ((dscale.to(scale_dtype)) / int_threshold -> quot_dtype).to(dtype of x)
  * i.e. the backward of  scale = clamp_min_ste(stat) / int_threshold  (B/core/quant/int.py:160,
- * B/core/restrict_val.py:22-42) with torch's rounding points, without the three tiny launches. */
-int bvq_stat_tie_apply_dscale(int dtype, const void* x, const void* stat, const float* dscale,
+ * B/core/restrict_val.py:22-42) with torch's rounding points, without the three tiny launches.
+ * pre_op: the statistic was taken of pre_op(x); the deposit's sign is sgn(pre_op(x)). */
+int bvq_stat_tie_apply_dscale(int pre_op, int dtype, const void* x, const void* stat, const float* dscale,
                               int scale_dtype, double int_threshold, int quot_dtype,
                               const int64_t* tie_info, const int64_t* total_ties, void* dx, int64_t outer,
                               int64_t channels, int64_t inner, bvq_stream_t stream);

@@ -20,6 +20,7 @@ ROUND, FLOOR, CEIL, ROUND_TO_ZERO, DPU_ROUND = range(5)
 STAT_ABSMAX, STAT_MINMAX = 0, 1
 SCALAR_OPMATH, SCALAR_CAST = 0, 1
 OUT_DEQUANT, OUT_INT = 0, 1
+PRE_NONE, PRE_RELU = 0, 1
 
 
 class QuantDesc(ctypes.Structure):
@@ -29,7 +30,7 @@ class QuantDesc(ctypes.Structure):
         ('zp_dtype', ctypes.c_int32), ('scale_per_channel', ctypes.c_int32),
         ('zp_per_channel', ctypes.c_int32), ('qmin', ctypes.c_float), ('qmax', ctypes.c_float),
         ('round_mode', ctypes.c_int32), ('scalar_mode', ctypes.c_int32), ('clamp_ste', ctypes.c_int32),
-        ('out_kind', ctypes.c_int32)]
+        ('out_kind', ctypes.c_int32), ('pre_op', ctypes.c_int32)]
 
 
 def build(force=False):
@@ -143,11 +144,11 @@ def abs_binary_sign_grad_bwd(g, x, dt):
 
 # ---- statistics -----------------------------------------------------------------------------------
 
-def stats(kind, x, dt, outer, channels, inner):
+def stats(kind, x, dt, outer, channels, inner, pre_op=PRE_NONE):
     x = _c(x, dt)
     assert x.size == outer * channels * inner
     out = np.empty(channels * (2 if kind == STAT_MINMAX else 1), dtype=np.float32)
-    lib().orc_stats(kind, dt, _ptr(x), ctypes.c_int64(outer), ctypes.c_int64(channels),
+    lib().orc_stats(kind, pre_op, dt, _ptr(x), ctypes.c_int64(outer), ctypes.c_int64(channels),
                     ctypes.c_int64(inner), _ptr(out))
     return out
 
@@ -164,10 +165,11 @@ def absmax_bwd(x, stat, gstat, dt, outer, channels, inner):
 
 def make_desc(outer, channels, inner, x_dtype, ct_dtype, scale_dtype, zp_dtype=F32,
               scale_per_channel=False, zp_per_channel=False, qmin=-128.0, qmax=127.0,
-              round_mode=ROUND, scalar_mode=SCALAR_OPMATH, clamp_ste=False, out_kind=OUT_DEQUANT):
+              round_mode=ROUND, scalar_mode=SCALAR_OPMATH, clamp_ste=False, out_kind=OUT_DEQUANT,
+              pre_op=PRE_NONE):
     return QuantDesc(outer, channels, inner, x_dtype, ct_dtype, scale_dtype, zp_dtype,
                      int(scale_per_channel), int(zp_per_channel), qmin, qmax, round_mode, scalar_mode,
-                     int(clamp_ste), out_kind)
+                     int(clamp_ste), out_kind, pre_op)
 
 
 def fakequant_fwd(desc, x, scale, zp, want_codes=True):

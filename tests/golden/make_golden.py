@@ -409,10 +409,81 @@ def gen_graphs():
     st.save()
 
 
+# ------------------------------------------------------------------------------------------------
+# E. activation function + quantizer (FusedActivationQuantProxy, B/proxy/runtime_quant.py:73-84) and
+#    externally scaled quantizers (bias quantization, B/core/quant/int.py:17-91)
+# ------------------------------------------------------------------------------------------------
+def gen_act_fused():
+    from brevitas.core.function_wrapper import Identity
+    from brevitas.core.quant import PrescaledRestrictIntQuant, PrescaledRestrictIntQuantWithInputBitWidth
+    st = Store('act_fused')
+
+    def uint_quant(scaling, signed):
+        return RescalingIntQuant(
+            IntQuant(narrow_range=False, signed=signed, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+            scaling, IntScaling(signed=signed, narrow_range=False), ZeroZeroPoint(), BitWidthConst(8))
+
+    for dn in ('f32', 'bf16'):
+        for signed in (False, True):
+            for tag, pc in (('per_tensor', None), ('per_channel', 6)):
+                if pc is None:
+                    view, stats, shape = OverTensorView(), AbsMax(), ()
+                else:
+                    view, stats, shape = OverOutputChannelView((1, 0, 2, 3)), AbsMax(1), (1, pc, 1, 1)
+                q = uint_quant(RuntimeStatsScaling(stats, view, FloatRestrictValue(), shape, False, 0.1, 1e-10), signed)
+                act = torch.nn.ReLU()
+                q.train()
+                for step in range(2):
+                    x = (torch.randn(4, 6, 5, 5) * (1.0 + step)).to(DT[dn])
+                    if step == 1 and pc is not None:
+                        x[:, 2] = -x[:, 2].abs()  # a channel that is entirely negative: statistic 0 -> min_val
+                    x.view(-1)[::17] = 0.0
+                    xi = x.clone().requires_grad_(True)
+                    y, scale, zp, bwt = q(act(xi))
+                    g = torch.randn(y.shape).to(y.dtype)
+                    y.backward(g)
+                    st.case({'graph': 'relu_runtime_stats', 'tag': tag, 'dtype': dn, 'signed': signed, 'step': step,
+                             'channels': pc},
+                            x=x, g=g, y=y, scale=scale, dx=xi.grad,
+                            running_stats=q.scaling_impl.runtime_stats.running_stats.clone())
+            # learned scale (steady state of Uint8ActPerTensorFloat after a ReLU)
+            q = uint_quant(ParameterScaling(2.5, None, FloatRestrictValue(), 1e-10), signed)
+            x = (torch.randn(4, 6, 5, 5) * 1.5).to(DT[dn])
+            xi = x.clone().requires_grad_(True)
+            y, scale, zp, bwt = q(torch.relu(xi))
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'graph': 'relu_parameter_scale', 'dtype': dn, 'signed': signed},
+                    x=x, g=g, y=y, scale=scale, dx=xi.grad, dvalue=q.scaling_impl.value.grad)
+    # externally scaled (bias) quantizers: doctest B/core/quant/int.py:32-48 and a per-channel case
+    q = PrescaledRestrictIntQuantWithInputBitWidth(IntQuant(narrow_range=True, signed=True), Identity())
+    x = torch.Tensor([0.042, -0.053, 0.31, -0.44])
+    y, scale, zp, bwt = q(x, torch.tensor(0.01), torch.tensor(4.))
+    st.case({'graph': 'prescaled_input_bit_width_doctest'}, x=x, y=y, scale=scale, zp=zp, bit_width=bwt)
+    for dn in ('f32', 'bf16'):
+        q = PrescaledRestrictIntQuant(IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(),
+                                               tensor_clamp_impl=TensorClamp()), BitWidthConst(8))
+        b = (torch.randn(16) * 0.5).to(DT[dn])
+        scale = (torch.rand(16) * 0.01 + 0.001).to(DT[dn])
+        bi = b.clone().requires_grad_(True)
+        si = scale.clone().requires_grad_(True)
+        y, so, zp, bwt = q(bi, si)
+        g = torch.randn(16).to(y.dtype)
+        y.backward(g)
+        st.case({'graph': 'prescaled_bias', 'dtype': dn}, x=b, scale=scale, g=g, y=y, dx=bi.grad, dscale=si.grad)
+    st.save()
+
+
 if __name__ == '__main__':
-    torch.manual_seed(123456)
     torch.set_num_threads(1)
-    gen_ste()
-    gen_int_quant()
-    gen_stats()
-    gen_graphs()
+    only = sys.argv[1:]
+    if not only or only != ['act_fused']:
+        # the first four files were generated in ONE run, in this order, from a single seed
+        torch.manual_seed(123456)
+        gen_ste()
+        gen_int_quant()
+        gen_stats()
+        gen_graphs()
+    if not only or 'act_fused' in only:
+        torch.manual_seed(123457)
+        gen_act_fused()

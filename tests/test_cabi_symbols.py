@@ -37,9 +37,9 @@ def test_abi_version_and_error_channel():
     assert rc < 0 and nat.last_error()
     rc = nat.lib.bvq_fakequant_fwd(None, None, None, None, None, None, None)
     assert rc == -1 and 'descriptor' in nat.last_error()
-    d = nat.QuantDesc(1, 1, 16, nat.F32, nat.BF16, nat.F32, nat.F32, 0, 0, -128.0, 127.0, 0, 0, 0, 0)
+    d = nat.QuantDesc(1, 1, 16, nat.F32, nat.BF16, nat.F32, nat.F32, 0, 0, -128.0, 127.0, 0, 0, 0, 0, 0)
     assert nat.lib.bvq_fakequant_fwd(ctypes.byref(d), None, None, None, None, None, None) == -2  # f32 x cannot compute in bf16
-    d = nat.QuantDesc(1, 1, 16, nat.F32, nat.F32, nat.F32, nat.F32, 0, 0, -128.0, 127.0, 7, 0, 0, 0)
+    d = nat.QuantDesc(1, 1, 16, nat.F32, nat.F32, nat.F32, nat.F32, 0, 0, -128.0, 127.0, 7, 0, 0, 0, 0)
     assert nat.lib.bvq_fakequant_fwd(ctypes.byref(d), None, None, None, None, None, None) == -1  # bad round mode
     assert nat.lib.bvq_stats_workspace_bytes(0, nat.BF16, 256, 512, 3136) > 0
     assert nat.lib.bvq_tie_info_bytes(512) == 512 * 8
@@ -49,7 +49,7 @@ def test_abi_version_and_error_channel():
 def test_descriptor_layout_matches_header():
     """bvq_quant_desc: three int64 then twelve 4-byte fields, no padding surprises"""
     from brevitas_amd import _native as nat
-    assert ctypes.sizeof(nat.QuantDesc) == 3 * 8 + 12 * 4
+    assert ctypes.sizeof(nat.QuantDesc) == 3 * 8 + 14 * 4  # 13 int32/float fields + tail padding to 8
     assert nat.QuantDesc.qmin.offset == 3 * 8 + 6 * 4
 
 

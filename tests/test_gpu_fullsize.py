@@ -58,9 +58,10 @@ def test_full_size_per_channel_properties(nat, act):
     t = torch.where(t < -128.0, torch.full_like(t, -128.0), t)
     assert torch.equal(bits(y), bits((t * sb).reshape(-1)))
     assert torch.equal(codes, t.reshape(-1).to(torch.int32))
-    # idempotence: a dequantized tensor is a fixed point of its own quantizer
+    # idempotence: a dequantized tensor is a fixed point of its own quantizer (as values: -0.0, which
+    # small negative inputs produce, re-quantizes to +0.0 through the "+ zero_point" of the chain)
     y2 = nat.fakequant_fwd(d, y, scale, zp)
-    assert torch.equal(bits(y2), bits(y))
+    assert torch.equal(y2, y)
     # shard independence: quantizing half the batch with the same scale gives that half of y
     dh = nat.QuantDesc(N // 2, C, inner, nat.BF16, nat.BF16, nat.BF16, nat.F32, 1, 0, -128.0, 127.0, 0, 0, 0, 0)
     half = flat.numel() // 2
@@ -122,12 +123,23 @@ def test_full_size_module_fused_equals_op_by_op(act):
         yf, sf, dxf, rf = outs[(True, per_channel)]
         yg, sg, dxg, rg = outs[(False, per_channel)]
         assert torch.equal(bits(yf), bits(yg)) and torch.equal(sf, sg) and torch.equal(rf, rg)
-        # dx: identical except at the (<= a few per channel) arg-max deposits, which carry a reduced sum
+        # dx: identical except at the (<= a few per channel) arg-max deposits.  The deposit is
+        # (sum g*q - sum dt*(x/s)/s) / 128: the op-by-op route rounds each of the two ~4e4-sized sums to
+        # bf16 before they cancel, the fused kernel keeps them in float32 -- so the bound is a few bf16
+        # ulps of the LARGER partial sum, not of the (much smaller) difference.
         diff = (bits(dxf) != bits(dxg)).reshape(-1).nonzero().reshape(-1)
         assert diff.numel() <= (x.shape[1] if per_channel else 64), diff.numel()
         if diff.numel():
-            a, b = dxf.reshape(-1)[diff].float(), dxg.reshape(-1)[diff].float()
-            assert bool(((a - b).abs() <= 2.0 ** -6 * (b.abs() + a.abs() + 1.0)).all())
+            N, C, H, W = x.shape
+            sb = sf.reshape(1, -1, 1, 1).to(x.dtype) if per_channel else sf.to(x.dtype)
+            q = torch.clamp(torch.round(x / sb), -128.0, 127.0)
+            dims = (0, 2, 3) if per_channel else (0, 1, 2, 3)
+            s1 = (g * q).double().sum(dim=dims).abs().reshape(-1)
+            s2 = ((g * sb) * ((x / sb) / sb)).double().sum(dim=dims).abs().reshape(-1)
+            bound = 2.0 ** -6 * (s1 + s2) / 128.0 + 1e-3
+            ch = ((diff // (H * W)) % C) if per_channel else torch.zeros_like(diff)
+            a, b = dxf.reshape(-1)[diff].double(), dxg.reshape(-1)[diff].double()
+            assert bool(((a - b).abs() <= bound[ch]).all()), ((a - b).abs().max(), bound.max())
 
 
 @pytest.mark.parametrize('shape,dtype,bit_width', [((512, 512, 3, 3), torch.float32, 8),       # config 2

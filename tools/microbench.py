@@ -52,5 +52,40 @@ def main():
         del x, g, y
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and 'small' not in sys.argv:
     main()
+
+
+def small_tensor_latency():
+    """weights are launch/latency-bound: wall-clock per fwd+bwd of the module-level quantizers"""
+    import time
+
+    import brevitas_amd.quant as Q
+    dev = 'cuda:0'
+    for name, shape, dt, bw in (('conv W [512,512,3,3] f32 int8', (512, 512, 3, 3), torch.float32, 8),
+                                ('linear W [8192,8192] bf16 int4', (8192, 8192), torch.bfloat16, 4),
+                                ('conv W [256,1024,1,1] bf16 int8', (256, 1024, 1, 1), torch.bfloat16, 8)):
+        w = torch.nn.Parameter((torch.randn(shape, device=dev) * 0.02).to(dt))
+        g = torch.randn(shape, device=dev).to(dt)
+        q = Q.Int8WeightPerChannelFloat(w, bw).to(dev)
+
+        def step():
+            w.grad = None
+            y = q(w)[0]
+            y.backward(g)
+
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 50
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / n * 1e6
+        t_gpu = timeit(step, iters=20, warm=2) * 1e3
+        print('%-34s wall %.0f us / step, device %.0f us / step (%d elements)' % (name, wall, t_gpu, w.numel()))
+
+
+if __name__ == '__main__' and 'small' in sys.argv:
+    small_tensor_latency()
