@@ -23,6 +23,7 @@ STAT_ABSMAX, STAT_MINMAX = 0, 1
 SCALAR_OPMATH, SCALAR_CAST = 0, 1
 OUT_DEQUANT, OUT_INT = 0, 1
 MATCH_ABS, MATCH_VALUE = 0, 1
+MATCH_FIRST = 16  # OR-ed: only the first attaining element, even for a whole-tensor reduction
 PRE_NONE, PRE_RELU = 0, 1
 ABI_VERSION = 1
 
@@ -31,7 +32,7 @@ _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 EXPORTS = (
     'bvq_abi_version', 'bvq_last_error', 'bvq_unary', 'bvq_stats_pre', 'bvq_scalar_clamp', 'bvq_tensor_clamp',
     'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
-    'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
+    'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
 
 
 class QuantDesc(ctypes.Structure):
@@ -73,6 +74,8 @@ def _load(path=None):
         'bvq_fakequant_bwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
         'bvq_absmax_scale': (i32, [i32, i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
         'bvq_running_stats_update': (i32, [i32, vp, i32, vp, i64, dbl, i32, vp]),
+        'bvq_kth_workspace_bytes': (i64, [i32, i64, i64, i64]),
+        'bvq_kth_value': (i32, [i32, i32, vp, i64, i64, i64, i64, vp, vp, i64, vp]),
         'bvq_tie_info_bytes': (i64, [i64]),
         'bvq_stat_tie_scan': (i32, [i32, i32, vp, vp, i64, i64, i64, vp, vp, vp]),
         'bvq_stat_tie_apply': (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
@@ -282,6 +285,26 @@ def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype,
         if _timer is not None:
             _timer.after('bvq_stats')
     return stat, scale
+
+
+def kth_value(x, k, outer, channels, inner, abs_key):
+    """exact k-th smallest (1-indexed) of |x| or x per channel of x[outer, channels, inner] -> [channels]"""
+    dev = require_device(x)
+    assert x.is_contiguous() and x.numel() == outer * channels * inner
+    dt = dtype_code(x.dtype)
+    out = torch.empty(channels, dtype=x.dtype, device=dev)
+    wsb = int(lib.bvq_kth_workspace_bytes(dt, outer, channels, inner))
+    if wsb < 0:
+        raise BvqError('bvq_kth_workspace_bytes: bad arguments')
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        if _timer is not None:
+            _timer.before('bvq_kth_value')
+        check(lib.bvq_kth_value(int(abs_key), dt, ptr(x), outer, channels, inner, int(k), ptr(out), ptr(ws), wsb,
+                                stream_ptr(dev)), 'bvq_kth_value')
+        if _timer is not None:
+            _timer.after('bvq_kth_value')
+    return out
 
 
 def running_stats_update(running, stat, momentum, first_batch):

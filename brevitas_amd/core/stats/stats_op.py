@@ -5,6 +5,7 @@ Backward: what autograd derives from torch.max / torch.min / torch.abs in the re
 gradient lands on the elements attaining the extremum (first one along a reduced dim, evenly over
 all ties for a whole-tensor reduction).
 """
+import math
 from typing import Optional
 
 import torch
@@ -83,6 +84,92 @@ def _unrows(dx_flat: Tensor, x: Tensor, dim: Optional[int]) -> Tensor:
     dim = dim % x.dim()
     moved_shape = tuple(s for i, s in enumerate(x.shape) if i != dim) + (x.shape[dim],)
     return dx_flat.reshape(moved_shape).movedim(-1, dim)
+
+
+class _KthValueFn(Function):
+    """k-th smallest of |x| (abs_key) or x: torch.kthvalue(k).values on the flat input or along `dim` of a
+    2-D one.  Backward: the gradient goes to one element attaining the value -- the first in memory
+    order (torch's choice among equal values is implementation-defined)."""
+
+    @staticmethod
+    def forward(ctx, x, k, dim, abs_key):
+        xc, outer, ch, inner, out_shape = _as_rows(x, dim)
+        val = nat.kth_value(xc.reshape(-1), k, outer, ch, inner, abs_key)
+        ctx.layout = (outer, ch, inner, dim, abs_key)
+        ctx.save_for_backward(x, val)
+        return val.reshape(out_shape)
+
+    @staticmethod
+    def backward(ctx, gval):
+        x, val = ctx.saved_tensors
+        outer, ch, inner, dim, abs_key = ctx.layout
+        xc, _, _, _, _ = _as_rows(x, dim)
+        match = (nat.MATCH_ABS if abs_key else nat.MATCH_VALUE) | nat.MATCH_FIRST
+        dx = nat.stat_bwd(match, xc.reshape(-1), val, gval.reshape(-1), outer, ch, inner)
+        return _unrows(dx, x, dim), None, None, None
+
+
+def _kth(x: Tensor, k: int, dim: Optional[int], abs_key: bool) -> Tensor:
+    return _KthValueFn.apply(x, k, dim, abs_key)
+
+
+def _numel_along(x: Tensor, dim: Optional[int]) -> int:
+    """how many elements each k-th value is selected from"""
+    if dim is None:
+        return x.numel()
+    assert len(x.size()) == 2, "Only 2-dim input is supported."
+    return x.shape[dim]
+
+
+class AbsPercentile(torch.nn.Module):
+    """high_percentile_q-th percentile of |x| (B/core/stats/stats_op.py:41-66): the k-th smallest with
+    k = floor(.01 * q * n + 0.5), an exact radix select on the device instead of torch.kthvalue"""
+
+    def __init__(self, high_percentile_q: float, stats_reduce_dim: Optional[int], percentile_q=None):
+        super().__init__()
+        if percentile_q is not None:
+            raise RuntimeError("percentile_q is deprecated, please pass high_percentile_q.")
+        assert high_percentile_q <= 100, "q has to be a percentage"
+        self.q = high_percentile_q
+        self.stats_reduce_dim = stats_reduce_dim
+
+    def forward(self, x: Tensor):
+        # k is 1-indexed, so round away from zero
+        k = int(math.floor(.01 * self.q * _numel_along(x, self.stats_reduce_dim) + 0.5))
+        return _kth(x, k, self.stats_reduce_dim, True)
+
+
+class NegativePercentileOrZero(torch.nn.Module):
+    """min(low_percentile_q-th percentile of x, 0) (B/core/stats/stats_op.py:69-94)"""
+
+    def __init__(self, low_percentile_q, stats_reduce_dim: Optional[int] = None) -> None:
+        super().__init__()
+        self.stats_reduce_dim = stats_reduce_dim
+        self.q = low_percentile_q
+
+    def forward(self, x: Tensor) -> Tensor:
+        k = int(math.ceil(.01 * self.q * _numel_along(x, self.stats_reduce_dim)))
+        result = _kth(x, k, self.stats_reduce_dim, False)
+        zero = torch.zeros((), dtype=result.dtype, device=result.device)
+        return torch.where(result <= zero, result, zero)
+
+
+class PercentileInterval(torch.nn.Module):
+    """|high percentile - low percentile| of x (B/core/stats/stats_op.py:97-126)"""
+
+    def __init__(self, low_percentile_q, high_percentile_q, stats_reduce_dim: Optional[int] = None) -> None:
+        super().__init__()
+        self.stats_reduce_dim = stats_reduce_dim
+        self.low_q = low_percentile_q
+        self.high_q = high_percentile_q
+
+    def forward(self, x: Tensor) -> Tensor:
+        n = _numel_along(x, self.stats_reduce_dim)
+        low_k = int(math.ceil(.01 * self.low_q * n))
+        high_k = int(math.floor(.01 * self.high_q * n + 0.5))
+        low_result = _kth(x, low_k, self.stats_reduce_dim, False)
+        high_result = _kth(x, high_k, self.stats_reduce_dim, False)
+        return torch.abs(high_result - low_result)
 
 
 class AbsMax(torch.nn.Module):

@@ -18,8 +18,11 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, 'libbvq.so')
 OBJ_DIR = os.path.join(ROOT, 'build', 'bvq')
 
-SOURCES = ['bvq_common.hip', 'bvq_elementwise.hip', 'bvq_stats.hip', 'bvq_fakequant.hip']
-HEADERS = ['bvq_common.h', 'bvq_quant_math.h', os.path.join(ROOT, 'include', 'bvq.h')]
+# (source, extra -D flags, object name): the quantizer file is split into its forward and backward halves
+SOURCES = [('bvq_common.hip', [], 'bvq_common.o'), ('bvq_elementwise.hip', [], 'bvq_elementwise.o'),
+           ('bvq_stats.hip', [], 'bvq_stats.o'), ('bvq_select.hip', [], 'bvq_select.o'), ('bvq_fakequant.hip', ['BVQ_PART=1'], 'bvq_fakequant_fwd.o'),
+           ('bvq_fakequant.hip', ['BVQ_PART=2'], 'bvq_fakequant_bwd.o')]
+HEADERS = ['bvq_common.h', 'bvq_quant_math.h', 'bvq_ties.h', os.path.join(ROOT, 'include', 'bvq.h')]
 
 # -ffp-contract=off: the reference rounds after every op; a contracted mul+add would not.
 # hipcc's default fp32 division is correctly rounded (no -ffast-math, no approximate reciprocal).
@@ -38,7 +41,7 @@ def _hipcc():
 
 def _digest():
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS + [os.path.abspath(__file__)]:
+    for f in sorted(set(src for src, _, _ in SOURCES)) + HEADERS + [os.path.abspath(__file__)]:
         path = f if os.path.isabs(f) else os.path.join(CSRC, f)
         with open(path, 'rb') as fh:
             h.update(fh.read())
@@ -59,9 +62,11 @@ def build(force=False, verbose=False, defines=(), out=None):
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
 
-    def compile_one(src):
-        obj = os.path.join(obj_dir, src.replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + ['-D' + d for d in defines] + ['-c', os.path.join(CSRC, src), '-o', obj]
+    def compile_one(item):
+        src, part_defines, objname = item
+        obj = os.path.join(obj_dir, objname)
+        cmd = [hipcc] + FLAGS + ['-D' + d for d in list(defines) + part_defines] + \
+            ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -71,7 +76,7 @@ def build(force=False, verbose=False, defines=(), out=None):
             print(r.stderr, flush=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path + '.tmp'] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)

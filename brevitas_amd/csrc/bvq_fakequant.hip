@@ -88,6 +88,13 @@ __device__ __forceinline__ bool bf16_fast_ok(float s, float z) {
          __builtin_bit_cast(uint32_t, z) == 0u;
 }
 
+// This file is compiled twice (brevitas_amd/csrc/build.py): BVQ_PART=1 holds the forward kernels and
+// entry point, BVQ_PART=2 the backward ones -- two translation units build in parallel.
+#ifndef BVQ_PART
+#define BVQ_PART 0  // 0: everything in one translation unit
+#endif
+
+#if BVQ_PART == 0 || BVQ_PART == 1
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -185,6 +192,9 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
     fwd_unit<XT, CT, VEC, RM, NT, false, false>(a, u, DivExact{s}, s, z, qmin, qmax);
 }
 
+#endif  // forward part
+
+#if BVQ_PART == 0 || BVQ_PART == 2
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
@@ -366,6 +376,8 @@ __global__ __launch_bounds__(kBlock) void channel_sum_kernel(const float* __rest
   }
 }
 
+#endif  // backward part
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -432,6 +444,7 @@ static void fill_args(QuantArgs& a, const bvq_quant_desc* d) {
 // instantiated vector widths: 16 bytes of x per lane, or one element (ragged / misaligned rows)
 static int snap_vec(int vec, int full) { return vec == full ? full : 1; }
 
+#if BVQ_PART == 0 || BVQ_PART == 1
 template <typename XT, typename CT>
 static void launch_fwd(const QuantArgs& a, int vec, bool nt, hipStream_t st) {
   constexpr int V = elem<XT>::vec;
@@ -454,6 +467,9 @@ static void launch_fwd(const QuantArgs& a, int vec, bool nt, hipStream_t st) {
   }
 }
 
+#endif
+
+#if BVQ_PART == 0 || BVQ_PART == 2
 template <typename XT, typename CT, int MODE>
 static void launch_bwd_mode(const QuantArgs& a, int vec, bool nt, hipStream_t st) {
   constexpr int V = elem<XT>::vec;
@@ -494,6 +510,8 @@ static void launch_bwd(const QuantArgs& a, int vec, int mode, bool nt, hipStream
   }
 }
 
+#endif
+
 #define BVQ_DISPATCH_PAIR(d, CALL)                                      \
   do {                                                                  \
     if ((d)->x_dtype == BVQ_F32) {                                      \
@@ -513,6 +531,7 @@ static void launch_bwd(const QuantArgs& a, int vec, int mode, bool nt, hipStream
 
 using namespace bvq;
 
+#if BVQ_PART == 0 || BVQ_PART == 1
 extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const void* scale,
                                  const void* zp, void* y, int32_t* codes, bvq_stream_t stream) {
   int rc = validate(d);
@@ -546,6 +565,9 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
   return check_launch("bvq_fakequant_fwd");
 }
 
+#endif  // forward part
+
+#if BVQ_PART == 0 || BVQ_PART == 2
 static int64_t bwd_units(const bvq_quant_desc* d) {
   int64_t outer, row_len;
   int32_t channels;
@@ -636,3 +658,5 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   }
   return rc;
 }
+
+#endif  // backward part

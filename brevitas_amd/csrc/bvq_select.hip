@@ -1,0 +1,294 @@
+// bvq_select.hip -- exact k-th value per channel (percentile statistics) by MSD radix select.
+//
+// Replaces torch.kthvalue on |x| or x (AbsPercentile / NegativePercentileOrZero / PercentileInterval,
+// B/core/stats/stats_op.py:41-126), which the default activation quantizer
+// (Int8ActPerTensorFloat: AbsPercentile(99.999), B/quant/base.py:68-75) runs on every one of its
+// first 300 training steps -- a sort-class kernel over the whole activation in the reference.
+//
+// Values are mapped to order-preserving unsigned keys (16 bits for bf16/f16, 32 for f32; every NaN
+// sorts last, as torch.kthvalue orders them) and the k-th key is found digit by digit from the top:
+// each pass streams x once, histograms one 11-bit digit of the keys that match the prefix found so
+// far (LDS, one private 2048-bin histogram per wave, flushed with global atomics), and a tiny
+// kernel picks the bin that holds the k-th element.  16-bit types need 2 passes (11 + 5 bits), f32
+// 3 (11 + 11 + 10); after the first pass almost no key matches the prefix, so later passes are pure
+// streaming reads.  Algorithmic bytes per element: passes * sizeof(x).  The result is exact.
+#include "bvq_common.h"
+#include "bvq_ties.h"
+
+namespace bvq {
+
+constexpr int kDigitBits = 11;
+constexpr int kBins = 1 << kDigitBits;
+constexpr int kSelUnroll = 4;
+
+// order-preserving key of a value
+template <typename T, bool ABS>
+__device__ __forceinline__ uint32_t sel_key(T v);
+
+template <>
+__device__ __forceinline__ uint32_t sel_key<float, true>(float v) {
+  return __builtin_bit_cast(uint32_t, v) & 0x7fffffffu;  // NaN patterns exceed +inf
+}
+template <>
+__device__ __forceinline__ uint32_t sel_key<float, false>(float v) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, v);
+  if (v != v) return 0xffffffffu;
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+template <typename T, bool ABS>
+__device__ __forceinline__ uint32_t sel_key16(T v) {
+  const uint32_t b = __builtin_bit_cast(uint16_t, v);
+  if (ABS) return b & 0x7fffu;
+  if (to_f<T>(v) != to_f<T>(v)) return 0xffffu;
+  return b ^ ((b & 0x8000u) ? 0xffffu : 0x8000u);
+}
+template <>
+__device__ __forceinline__ uint32_t sel_key<bf16_t, true>(bf16_t v) {
+  return sel_key16<bf16_t, true>(v);
+}
+template <>
+__device__ __forceinline__ uint32_t sel_key<bf16_t, false>(bf16_t v) {
+  return sel_key16<bf16_t, false>(v);
+}
+template <>
+__device__ __forceinline__ uint32_t sel_key<f16_t, true>(f16_t v) {
+  return sel_key16<f16_t, true>(v);
+}
+template <>
+__device__ __forceinline__ uint32_t sel_key<f16_t, false>(f16_t v) {
+  return sel_key16<f16_t, false>(v);
+}
+
+struct SelArgs {
+  Tiling t;
+  const void* x;
+  const uint32_t* prefix;  // [channels] key bits fixed by earlier passes (already shifted down)
+  uint32_t* hist;          // [channels][kBins] of this pass
+  int32_t shift;           // this pass looks at (key >> shift) & (kBins - 1) ...
+  int32_t bits;            // ... of which `bits` low bits are significant (last pass may be narrower)
+  int32_t first_pass;      // no prefix to match yet
+};
+
+template <typename T, int VEC, bool ABS, bool NT>
+__global__ __launch_bounds__(kBlock) void kth_hist_kernel(SelArgs a) {
+  __shared__ uint32_t lds[kWavesPerBlock][kBins];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  uint32_t* h = lds[wave];
+  for (int b = lane; b < kBins; b += kWave) h[b] = 0;
+  __syncthreads();  // every wave reaches this (the unit check comes after)
+  const Unit u = locate_unit(a.t);
+  if (!u.valid) return;
+  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + u.base;
+  const uint32_t want = a.first_pass ? 0u : a.prefix[u.channel];
+  const int hi_shift = a.shift + a.bits;  // bits above this pass's digit
+  const uint32_t mask = (1u << a.bits) - 1u;
+  ChunkCursor cur;
+  cur.init(u, VEC, lane);
+  const int64_t total = (int64_t)u.nrows * cur.cpr;
+  for (int64_t done = 0; done < total; done += (int64_t)kWave * kSelUnroll) {
+    vec_t<T, VEC> xv[kSelUnroll];
+    bool ok[kSelUnroll];
+#pragma unroll
+    for (int j = 0; j < kSelUnroll; ++j) {
+      ok[j] = cur.valid();
+      if (ok[j]) xv[j] = load_vec<T, VEC, NT>(xp + cur.offset(u.row_stride, VEC));
+      cur.next();
+    }
+#pragma unroll
+    for (int j = 0; j < kSelUnroll; ++j) {
+      if (ok[j]) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const uint32_t key = sel_key<T, ABS>(xv[j].v[k]);
+          const bool match = a.first_pass || (hi_shift >= 32 ? true : (key >> hi_shift) == want);
+          if (match) atomicAdd(&h[(key >> a.shift) & mask], 1u);
+        }
+      }
+    }
+  }
+  const int64_t i = (int64_t)cur.cpr * VEC + lane;
+  if (u.nrows == 1 && i < u.len) {
+    const uint32_t key = sel_key<T, ABS>(xp[i]);
+    const bool match = a.first_pass || (hi_shift >= 32 ? true : (key >> hi_shift) == want);
+    if (match) atomicAdd(&h[(key >> a.shift) & mask], 1u);
+  }
+  // flush the non-empty bins of this wave's histogram
+  uint32_t* gh = a.hist + (int64_t)u.channel * kBins;
+  for (int b = lane; b < kBins; b += kWave) {
+    const uint32_t c = h[b];
+    if (c) atomicAdd(&gh[b], c);
+  }
+}
+
+// one workgroup per channel: find the bin that holds the k-th (1-indexed) matching key, append its
+// digit to the prefix and make k relative to that bin
+__global__ __launch_bounds__(kBlock) void kth_pick_kernel(const uint32_t* __restrict__ hist,
+                                                          uint32_t* __restrict__ prefix,
+                                                          int64_t* __restrict__ krem, int32_t bits) {
+  __shared__ int64_t part[kBlock];
+  const int c = blockIdx.x;
+  const uint32_t* h = hist + (int64_t)c * kBins;
+  constexpr int kPer = kBins / kBlock;  // consecutive bins per thread
+  int64_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) mine += h[threadIdx.x * kPer + j];
+  part[threadIdx.x] = mine;
+  __syncthreads();
+  // exclusive prefix over the 256 partial sums (serial on one thread: 256 adds)
+  __shared__ int64_t before_me[kBlock];
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    for (int t = 0; t < kBlock; ++t) {
+      before_me[t] = run;
+      run += part[t];
+    }
+  }
+  __syncthreads();
+  const int64_t k = krem[c];
+  int64_t run = before_me[threadIdx.x];
+  if (k > run && k <= run + mine) {  // exactly one thread owns the k-th element
+    for (int j = 0; j < kPer; ++j) {
+      const int64_t cnt = h[threadIdx.x * kPer + j];
+      if (k <= run + cnt) {
+        prefix[c] = (prefix[c] << bits) | (uint32_t)(threadIdx.x * kPer + j);
+        krem[c] = k - run;
+        break;
+      }
+      run += cnt;
+    }
+  }
+}
+
+template <typename T, bool ABS>
+__global__ void kth_store_kernel(const uint32_t* __restrict__ prefix, void* out, int32_t channels) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= channels) return;
+  const uint32_t key = prefix[c];
+  T* o = reinterpret_cast<T*>(out);
+  if constexpr (sizeof(T) == 4) {
+    const uint32_t b = ABS ? key : ((key >> 31) ? (key ^ 0x80000000u) : ~key);
+    o[c] = __builtin_bit_cast(float, b);
+  } else {
+    const uint16_t b = (uint16_t)(ABS ? key : ((key & 0x8000u) ? (key ^ 0x8000u) : (~key & 0xffffu)));
+    o[c] = __builtin_bit_cast(T, b);
+  }
+}
+
+__global__ void kth_init_kernel(uint32_t* prefix, int64_t* krem, int64_t k, int32_t channels) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < channels) {
+    prefix[c] = 0;
+    krem[c] = k;
+  }
+}
+
+template <typename T, bool ABS>
+static void launch_hist(const SelArgs& a, int vec, bool nt, hipStream_t st) {
+  constexpr int V = elem<T>::vec;
+  const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
+  if (vec == V && nt)
+    kth_hist_kernel<T, V, ABS, true><<<grid, block, 0, st>>>(a);
+  else if (vec == V)
+    kth_hist_kernel<T, V, ABS, false><<<grid, block, 0, st>>>(a);
+  else
+    kth_hist_kernel<T, 1, ABS, false><<<grid, block, 0, st>>>(a);
+}
+
+}  // namespace bvq
+
+using namespace bvq;
+
+static int passes_for(int dtype) { return dtype == BVQ_F32 ? 3 : 2; }
+
+extern "C" int64_t bvq_kth_workspace_bytes(int dtype, int64_t outer, int64_t channels, int64_t inner) {
+  if (dtype < BVQ_F32 || dtype > BVQ_F16 || outer < 0 || channels < 1 || inner < 0) return -1;
+  return (int64_t)passes_for(dtype) * channels * kBins * (int64_t)sizeof(uint32_t) +
+         channels * (int64_t)(sizeof(uint32_t) + sizeof(int64_t)) + 256;
+}
+
+extern "C" int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t outer, int64_t channels,
+                             int64_t inner, int64_t k, void* out, void* workspace,
+                             int64_t workspace_bytes, bvq_stream_t stream) {
+  if (dtype < BVQ_F32 || dtype > BVQ_F16 || outer < 0 || channels < 1 || inner < 0) {
+    set_error("bvq_kth_value: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  const int64_t per_channel = outer * inner;
+  if (k < 1 || k > per_channel) {  // torch.kthvalue: "selected index k out of range"
+    set_error("bvq_kth_value: k = %lld out of range [1, %lld]", (long long)k, (long long)per_channel);
+    return BVQ_ERR_INVALID;
+  }
+  if (!x || !out || !workspace) {
+    set_error("bvq_kth_value: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  const int64_t need = bvq_kth_workspace_bytes(dtype, outer, channels, inner);
+  if (workspace_bytes < need) {
+    set_error("bvq_kth_value: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    return BVQ_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int passes = passes_for(dtype);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(workspace);
+  const int64_t hist_words = (int64_t)passes * channels * kBins;
+  // keep the int64 array 8-byte aligned
+  int64_t* krem = reinterpret_cast<int64_t*>(hist + ((hist_words + 1) / 2) * 2);
+  uint32_t* prefix = reinterpret_cast<uint32_t*>(krem + channels);
+  (void)hipMemsetAsync(hist, 0, (size_t)hist_words * sizeof(uint32_t), st);
+  kth_init_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, st>>>(prefix, krem, k,
+                                                                                  (int32_t)channels);
+  const int64_t t_outer = channels > 1 ? outer : 1;
+  const int64_t row_len = channels > 1 ? inner : outer * inner;
+  const int full = 16 / dtype_size(dtype);
+  const void* ptrs[1] = {x};
+  const int els[1] = {dtype_size(dtype)};
+  int vec = pick_vec(full, t_outer * channels, row_len, ptrs, els, 1);
+  vec = vec == full ? full : 1;
+  SelArgs a;
+  a.t = make_tiling(t_outer, (int32_t)channels, row_len, vec);
+  a.x = x;
+  a.prefix = prefix;
+  const bool nt = outer * channels * inner * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
+  const int key_bits = dtype == BVQ_F32 ? 32 : 16;
+  int done_bits = 0;
+  for (int p = 0; p < passes; ++p) {
+    const int bits = (key_bits - done_bits) < kDigitBits ? (key_bits - done_bits) : kDigitBits;
+    a.hist = hist + (int64_t)p * channels * kBins;
+    a.bits = bits;
+    a.shift = key_bits - done_bits - bits;
+    a.first_pass = p == 0;
+#define BVQ_HIST(T)                             \
+  do {                                          \
+    if (abs_key)                                \
+      launch_hist<T, true>(a, vec, nt, st);     \
+    else                                        \
+      launch_hist<T, false>(a, vec, nt, st);    \
+  } while (0)
+    if (dtype == BVQ_F32)
+      BVQ_HIST(float);
+    else if (dtype == BVQ_BF16)
+      BVQ_HIST(bf16_t);
+    else
+      BVQ_HIST(f16_t);
+#undef BVQ_HIST
+    kth_pick_kernel<<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(a.hist, prefix, krem, bits);
+    done_bits += bits;
+  }
+  const unsigned nb = (unsigned)((channels + 255) / 256);
+#define BVQ_STORE(T)                                                                     \
+  do {                                                                                   \
+    if (abs_key)                                                                         \
+      kth_store_kernel<T, true><<<dim3(nb), dim3(256), 0, st>>>(prefix, out, (int32_t)channels); \
+    else                                                                                 \
+      kth_store_kernel<T, false><<<dim3(nb), dim3(256), 0, st>>>(prefix, out, (int32_t)channels); \
+  } while (0)
+  if (dtype == BVQ_F32)
+    BVQ_STORE(float);
+  else if (dtype == BVQ_BF16)
+    BVQ_STORE(bf16_t);
+  else
+    BVQ_STORE(f16_t);
+#undef BVQ_STORE
+  return check_launch("bvq_kth_value");
+}

@@ -253,14 +253,15 @@ __device__ __forceinline__ T zero_like(T v) {
 
 template <typename T, int VEC, int MATCH, bool WRITE_ZERO>
 __global__ __launch_bounds__(kBlock) void tie_scan_kernel(Tiling t, const void* x, const void* stat,
-                                                          unsigned long long* info, void* dx) {
+                                                          unsigned long long* info, void* dx,
+                                                          int first_only) {
   const Unit u = locate_unit(t);
   if (!u.valid) return;
   const int lane = threadIdx.x & 63;
   const T* __restrict__ xp = reinterpret_cast<const T*>(x) + u.base;
   T* __restrict__ dp = reinterpret_cast<T*>(dx) + u.base;
   const T sv = reinterpret_cast<const T*>(stat)[u.channel];
-  const bool per_channel = t.channels > 1;
+  const bool per_channel = t.channels > 1 || first_only;  // record the first position only
   ChunkCursor cur;
   cur.init(u, VEC, lane);
   const int64_t total = (int64_t)u.nrows * cur.cpr;
@@ -289,17 +290,18 @@ __global__ __launch_bounds__(kBlock) void tie_scan_kernel(Tiling t, const void* 
   }
 }
 
-__global__ void tie_init_kernel(unsigned long long* info, int32_t channels) {
+__global__ void tie_init_kernel(unsigned long long* info, int32_t channels, int first_only) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (channels > 1) {
+  if (channels > 1 || first_only) {
     if (i < channels) info[i] = ~0ull;
   } else {
     if (i < 2) info[i] = 0ull;
   }
 }
 
-void launch_tie_init(unsigned long long* info, int64_t channels, hipStream_t st) {
-  tie_init_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, st>>>(info, (int32_t)channels);
+void launch_tie_init(unsigned long long* info, int64_t channels, hipStream_t st, int first_only) {
+  tie_init_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, st>>>(info, (int32_t)channels,
+                                                                                  first_only);
 }
 
 // Where the statistic's gradient comes from: an array of the statistic's dtype, or the float32
@@ -455,29 +457,31 @@ static void launch_stat(int kind, int pre_op, const StatArgs& a, int vec, bool n
 
 template <typename T, int MATCH, bool WZ>
 static void launch_tie_scan_v(const Tiling& t, int vec, const void* x, const void* stat,
-                              unsigned long long* info, void* dx, hipStream_t st) {
+                              unsigned long long* info, void* dx, int first_only, hipStream_t st) {
   constexpr int V = elem<T>::vec;
   const dim3 grid(grid_for_units(t.units)), block(kBlock);
   if (vec == V)
-    tie_scan_kernel<T, V, MATCH, WZ><<<grid, block, 0, st>>>(t, x, stat, info, dx);
+    tie_scan_kernel<T, V, MATCH, WZ><<<grid, block, 0, st>>>(t, x, stat, info, dx, first_only);
   else
-    tie_scan_kernel<T, 1, MATCH, WZ><<<grid, block, 0, st>>>(t, x, stat, info, dx);
+    tie_scan_kernel<T, 1, MATCH, WZ><<<grid, block, 0, st>>>(t, x, stat, info, dx, first_only);
 }
 
 template <typename T, int MATCH>
 static void run_tie_scan(const Tiling& t, int vec, const void* x, const void* stat,
-                         unsigned long long* info, void* dx, int write_zeros, hipStream_t st) {
+                         unsigned long long* info, void* dx, int write_zeros, int first_only,
+                         hipStream_t st) {
   if (write_zeros)
-    launch_tie_scan_v<T, MATCH, true>(t, vec, x, stat, info, dx, st);
+    launch_tie_scan_v<T, MATCH, true>(t, vec, x, stat, info, dx, first_only, st);
   else
-    launch_tie_scan_v<T, MATCH, false>(t, vec, x, stat, info, dx, st);
+    launch_tie_scan_v<T, MATCH, false>(t, vec, x, stat, info, dx, first_only, st);
 }
 
 template <typename T, int MATCH>
 static void run_tie_apply(const void* x, const void* stat, GstatSrc gstat,
                           const unsigned long long* info, const unsigned long long* total, void* dx,
-                          int64_t outer, int64_t channels, int64_t inner, int mode_add, hipStream_t st) {
-  if (channels > 1) {
+                          int64_t outer, int64_t channels, int64_t inner, int mode_add, int first_only,
+                          hipStream_t st) {
+  if (channels > 1 || first_only) {
     const unsigned nb = (unsigned)((channels + 255) / 256);
     tie_apply_first_kernel<T, MATCH><<<dim3(nb), dim3(256), 0, st>>>(x, gstat, info, dx, outer,
                                                                      (int32_t)channels, inner, mode_add);
@@ -658,8 +662,9 @@ extern "C" int bvq_running_stats_update(int run_dtype, void* running, int stat_d
     }                                                              \
   } while (0)
 
-static int check_stat_args(const char* fn, int match, int dtype, int64_t outer, int64_t channels,
+static int check_stat_args(const char* fn, int match_flags, int dtype, int64_t outer, int64_t channels,
                            int64_t inner) {
+  const int match = match_flags & ~BVQ_MATCH_FIRST;
   if (bad_dtype(dtype) || outer < 0 || channels < 1 || inner < 0 ||
       (match != BVQ_MATCH_ABS && match != BVQ_MATCH_VALUE)) {
     set_error("%s: bad argument", fn);
@@ -684,7 +689,9 @@ extern "C" int bvq_stat_tie_scan(int match, int dtype, const void* x, const void
   }
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* info = reinterpret_cast<unsigned long long*>(tie_info);
-  launch_tie_init(info, channels, st);
+  const int first_only = (match & BVQ_MATCH_FIRST) != 0;
+  match &= ~BVQ_MATCH_FIRST;
+  launch_tie_init(info, channels, st, first_only);
   if (outer * channels * inner == 0) return check_launch("bvq_stat_tie_scan");
   if (!x || !stat) {
     set_error("bvq_stat_tie_scan: null pointer");
@@ -693,7 +700,7 @@ extern "C" int bvq_stat_tie_scan(int match, int dtype, const void* x, const void
   int vec;
   const Tiling t = stat_tiling(dtype, x, dx_zero_fill, outer, channels, inner, vec);
   BVQ_DISPATCH_T_MATCH(dtype, match, run_tie_scan, t, vec, x, stat, info, dx_zero_fill,
-                       dx_zero_fill != nullptr, st);
+                       dx_zero_fill != nullptr, first_only, st);
   return check_launch("bvq_stat_tie_scan");
 }
 
@@ -712,10 +719,12 @@ extern "C" int bvq_stat_tie_apply(int match, int pre_op, int dtype, const void* 
   GstatSrc src = {};
   src.p = gstat;
   src.pre_relu = pre_op == BVQ_PRE_RELU;
+  const int first_only = (match & BVQ_MATCH_FIRST) != 0;
+  match &= ~BVQ_MATCH_FIRST;
   BVQ_DISPATCH_T_MATCH(dtype, match, run_tie_apply, x, stat, src,
                        reinterpret_cast<const unsigned long long*>(tie_info),
                        reinterpret_cast<const unsigned long long*>(total_ties), dx, outer, channels, inner,
-                       mode_add, st);
+                       mode_add, first_only, st);
   return check_launch("bvq_stat_tie_apply");
 }
 
@@ -747,7 +756,7 @@ extern "C" int bvq_stat_tie_apply_dscale(int pre_op, int dtype, const void* x, c
   BVQ_DISPATCH_T_MATCH(dtype, BVQ_MATCH_ABS, run_tie_apply, x, stat, src,
                        reinterpret_cast<const unsigned long long*>(tie_info),
                        reinterpret_cast<const unsigned long long*>(total_ties), dx, outer, channels, inner, 1,
-                       st);
+                       0, st);
   return check_launch("bvq_stat_tie_apply_dscale");
 }
 

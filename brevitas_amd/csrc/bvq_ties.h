@@ -54,6 +54,6 @@ __device__ __forceinline__ uint32_t pre_abs_bits(T v) {
   }
 }
 
-void launch_tie_init(unsigned long long* info, int64_t channels, hipStream_t st);
+void launch_tie_init(unsigned long long* info, int64_t channels, hipStream_t st, int first_only = 0);
 
 }  // namespace bvq

@@ -192,10 +192,23 @@ int bvq_absmax_scale(int pre_op, int dtype, const void* x, int64_t outer, int64_
 int bvq_running_stats_update(int run_dtype, void* running, int stat_dtype, const void* stat, int64_t n,
                              double momentum, int first_batch, bvq_stream_t stream);
 
+/* ---- percentile statistics ---------------------------------------------------------------------
+ * k-th smallest value (k is 1-indexed, the same for every channel) of |x| (abs_key = 1) or of x
+ * (abs_key = 0) over the `outer` and `inner` axes of x[outer, channels, inner]: torch.kthvalue on the
+ * flat tensor / along dim 1 of the [C, -1] view, as used by AbsPercentile, NegativePercentileOrZero and
+ * PercentileInterval (B/core/stats/stats_op.py:41-126).  Exact selection (MSD radix select: 2 streaming
+ * reads of x for 16-bit types, 3 for float32); NaNs order last.  out: dtype of x, `channels` elements. */
+int64_t bvq_kth_workspace_bytes(int dtype, int64_t outer, int64_t channels, int64_t inner);
+int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+                  int64_t k, void* out, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
+
 /* which elements attain the statistic */
 typedef enum bvq_match_kind {
-  BVQ_MATCH_ABS = 0,  /* |x| == stat, deposit scaled by sgn(x): torch.max(torch.abs(x)) (AbsMax)   */
-  BVQ_MATCH_VALUE = 1 /*  x  == stat: torch.max(x) / torch.min(x) (the two halves of AbsMinMax)    */
+  BVQ_MATCH_ABS = 0,   /* |x| == stat, deposit scaled by sgn(x): torch.max(torch.abs(x)) (AbsMax)   */
+  BVQ_MATCH_VALUE = 1, /*  x  == stat: torch.max(x) / torch.min(x) (the two halves of AbsMinMax)    */
+  /* OR-ed flag: even with channels == 1 only the FIRST attaining element receives the gradient (an
+   * index-returning reduction such as torch.kthvalue / torch.max(dim) over a flattened tensor) */
+  BVQ_MATCH_FIRST = 16
 } bvq_match_kind;
 
 /* Backward of a max / min statistic w.r.t. x, as autograd derives it from torch.max / torch.min

@@ -153,6 +153,16 @@ def stats(kind, x, dt, outer, channels, inner, pre_op=PRE_NONE):
     return out
 
 
+def kth_value(x, dt, outer, channels, inner, k, abs_key):
+    x = _c(x, dt)
+    out = np.empty(channels, dtype=np.float32)
+    rc = lib().orc_kth_value(int(abs_key), dt, _ptr(x), ctypes.c_int64(outer), ctypes.c_int64(channels),
+                             ctypes.c_int64(inner), ctypes.c_int64(k), _ptr(out))
+    if rc != 0:
+        raise ValueError('k out of range')
+    return out
+
+
 def absmax_bwd(x, stat, gstat, dt, outer, channels, inner):
     x, stat, gstat = _c(x, dt), _c(stat, dt), _c(gstat, dt)
     dx = np.empty_like(x)

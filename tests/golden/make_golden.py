@@ -474,10 +474,67 @@ def gen_act_fused():
     st.save()
 
 
+# ------------------------------------------------------------------------------------------------
+# F. percentile statistics (B/core/stats/stats_op.py:41-126) and the default Int8ActPerTensorFloat graph
+# ------------------------------------------------------------------------------------------------
+def gen_percentile():
+    from brevitas.core.stats import AbsPercentile, NegativePercentileOrZero, PercentileInterval
+    st = Store('percentile')
+    ten = torch.Tensor([1, 2, 3, 4, 5, 6, 7, 8, 9, 10])  # tests/brevitas/core/test_stats.py:12-30
+    for v in range(1, 11):
+        st.case({'stat': 'abs_percentile', 'q': v * 10, 'dim': None, 'tag': 'one_to_ten'}, x=ten,
+                out=AbsPercentile(v * 10, None)(ten))
+    st.case({'stat': 'abs_percentile', 'q': 90, 'dim': 1, 'tag': 'one_to_ten_x2'}, x=ten.repeat(2, 1),
+            out=AbsPercentile(90, stats_reduce_dim=1)(ten.repeat(2, 1)))
+    vals = torch.tensor([-1., -2., 5])  # test_stats.py:47-67
+    st.case({'stat': 'neg_percentile', 'q': 0.01, 'dim': None, 'tag': 'neg'}, x=vals,
+            out=NegativePercentileOrZero(0.01)(vals))
+    st.case({'stat': 'neg_percentile', 'q': 0.01, 'dim': None, 'tag': 'pos'}, x=torch.tensor([1., 2., 5]),
+            out=NegativePercentileOrZero(0.01)(torch.tensor([1., 2., 5])))
+    st.case({'stat': 'interval', 'low_q': 0.01, 'high_q': 99.9, 'dim': None, 'tag': 'one_to_ten'}, x=ten,
+            out=PercentileInterval(low_percentile_q=0.01, high_percentile_q=99.9)(ten))
+    for dn, dtype in DT.items():
+        for tag, shape in (('flat', (37, 91)), ('rows', (6, 500))):
+            x = torch.randn(shape) * 2
+            x.view(-1)[::13] = 0.0
+            if tag == 'flat':
+                x[3, 3] = float('inf')
+            x = x.to(dtype)
+            dims = (None,) if tag == 'flat' else (None, 1)
+            for dim in dims:
+                for q in (99.999, 99.0, 50.0, 3.0, 100.0):
+                    xi = x.clone().requires_grad_(True)
+                    out = AbsPercentile(q, dim)(xi)
+                    gout = torch.randn(out.shape).to(out.dtype)
+                    out.backward(gout)
+                    st.case({'stat': 'abs_percentile', 'q': q, 'dim': dim, 'tag': tag, 'dtype': dn},
+                            x=x, out=out, gout=gout, dx=xi.grad)
+                for q in (0.01, 10.0, 60.0):
+                    st.case({'stat': 'neg_percentile', 'q': q, 'dim': dim, 'tag': tag, 'dtype': dn}, x=x,
+                            out=NegativePercentileOrZero(q, dim)(x))
+                st.case({'stat': 'interval', 'low_q': 0.01, 'high_q': 99.9, 'dim': dim, 'tag': tag, 'dtype': dn},
+                        x=x, out=PercentileInterval(0.01, 99.9, dim)(x))
+    # the default activation quantizer: Int8ActPerTensorFloat = ParamFromRuntimePercentileScaling
+    # (AbsPercentile(99.999, None), collect 300 steps; here 2) -- B/quant/base.py:68-75, scaled_int.py:170-180
+    for dn in ('f32', 'bf16'):
+        q = RescalingIntQuant(
+            IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+            ParameterFromRuntimeStatsScaling(2, AbsPercentile(99.999, None), OverTensorView(), (),
+                                             FloatRestrictValue(), 0.1, 1e-10),
+            IntScaling(signed=True, narrow_range=False), ZeroZeroPoint(), BitWidthConst(8))
+        q.train()
+        for step in range(3):
+            x = (torch.randn(8, 6, 9, 9) * (1.0 + 0.5 * step)).to(DT[dn])
+            y, scale, zp, bwt = q(x)
+            st.case({'stat': 'int8_act_per_tensor_float', 'dtype': dn, 'step': step}, x=x, y=y, scale=scale,
+                    buffer=q.scaling_impl.buffer.clone(), value=q.scaling_impl.value.detach().clone())
+    st.save()
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     only = sys.argv[1:]
-    if not only or only != ['act_fused']:
+    if not only or not set(only) <= {'act_fused', 'percentile'}:
         # the first four files were generated in ONE run, in this order, from a single seed
         torch.manual_seed(123456)
         gen_ste()
@@ -487,3 +544,6 @@ if __name__ == '__main__':
     if not only or 'act_fused' in only:
         torch.manual_seed(123457)
         gen_act_fused()
+    if not only or 'percentile' in only:
+        torch.manual_seed(123458)
+        gen_percentile()
