@@ -25,6 +25,8 @@ OUT_DEQUANT, OUT_INT = 0, 1
 MATCH_ABS, MATCH_VALUE = 0, 1
 MATCH_FIRST = 16  # OR-ed: only the first attaining element, even for a whole-tensor reduction
 PRE_NONE, PRE_RELU = 0, 1
+CODES_I32, CODES_I8, CODES_U8 = 0, 1, 2
+_CODES_TORCH = {CODES_I32: torch.int32, CODES_I8: torch.int8, CODES_U8: torch.uint8}
 ABI_VERSION = 1
 
 _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
@@ -43,7 +45,7 @@ class QuantDesc(ctypes.Structure):
         ('zp_dtype', ctypes.c_int32), ('scale_per_channel', ctypes.c_int32),
         ('zp_per_channel', ctypes.c_int32), ('qmin', ctypes.c_float), ('qmax', ctypes.c_float),
         ('round_mode', ctypes.c_int32), ('scalar_mode', ctypes.c_int32), ('clamp_ste', ctypes.c_int32),
-        ('out_kind', ctypes.c_int32), ('pre_op', ctypes.c_int32)]
+        ('out_kind', ctypes.c_int32), ('pre_op', ctypes.c_int32), ('codes_dtype', ctypes.c_int32)]
 
 
 class BvqError(RuntimeError):
@@ -128,12 +130,37 @@ def require_device(*tensors):
     return dev
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_ptr(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """the current HIP stream of `device` as the void* the C ABI takes"""
+    if _raw_stream is not None:  # no Stream object construction on the hot path
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    """raw device address (ctypes converts the int for the c_void_p parameters)"""
+    return t.data_ptr() if t is not None else None
+
+
+class _DeviceGuard:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the common case costs one call)"""
+    __slots__ = ('ctx',)
+
+    def __init__(self, dev):
+        idx = dev.index
+        self.ctx = None if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 # Optional measurement hook (bench.py): an object with before(name) / after(name), called around the
@@ -152,7 +179,7 @@ def unary(op, x):
     dev = require_device(x)
     x = x.contiguous()
     y = torch.empty_like(x)
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         check(lib.bvq_unary(op, dtype_code(x.dtype), ptr(x), ptr(y), x.numel(), stream_ptr(dev)), 'bvq_unary')
     return y
 
@@ -161,7 +188,7 @@ def scalar_clamp(x, lo, hi):
     dev = require_device(x)
     x = x.contiguous()
     y = torch.empty_like(x)
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         check(lib.bvq_scalar_clamp(dtype_code(x.dtype), ptr(x), ptr(y), x.numel(),
                                    0.0 if lo is None else float(lo), int(lo is not None),
                                    0.0 if hi is None else float(hi), int(hi is not None), stream_ptr(dev)),
@@ -183,7 +210,7 @@ def tensor_clamp(x, lo, hi, out=None):
     xc = x.contiguous()
     lo, hi, full = _bounds(xc, lo, hi)
     y = out if out is not None else torch.empty_like(xc)
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         check(lib.bvq_tensor_clamp(dtype_code(xc.dtype), ptr(xc), ptr(lo), ptr(hi), full, ptr(y), xc.numel(),
                                    stream_ptr(dev)), 'bvq_tensor_clamp')
     return y
@@ -195,7 +222,7 @@ def tensor_clamp_bwd(g, x, lo, hi):
     g = g.to(xc.dtype).contiguous()
     lo, hi, full = _bounds(xc, lo, hi)
     dx = torch.empty_like(xc)
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         check(lib.bvq_tensor_clamp_bwd(dtype_code(xc.dtype), ptr(g), ptr(xc), ptr(lo), ptr(hi), full, ptr(dx),
                                        xc.numel(), stream_ptr(dev)), 'bvq_tensor_clamp_bwd')
     return dx
@@ -206,7 +233,7 @@ def abs_binary_sign_grad_bwd(g, x):
     xc = x.contiguous()
     g = g.to(xc.dtype).contiguous()
     dx = torch.empty_like(xc)
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         check(lib.bvq_abs_binary_sign_grad_bwd(dtype_code(xc.dtype), ptr(g), ptr(xc), ptr(dx), xc.numel(),
                                                stream_ptr(dev)), 'bvq_abs_binary_sign_grad_bwd')
     return dx
@@ -223,7 +250,7 @@ def stats(kind, x, outer, channels, inner, out_f32=False, pre_op=PRE_NONE):
     if wsb < 0:
         raise BvqError('bvq_stats_workspace_bytes: bad arguments')
     ws = torch.empty(max(int(wsb), 8), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         if _timer is not None:
             _timer.before('bvq_stats')
         check(lib.bvq_stats_pre(kind, pre_op, dt, ptr(x), outer, channels, inner, dtype_code(out.dtype), ptr(out),
@@ -246,24 +273,27 @@ def stat_bwd(match, x, stat, gstat, outer, channels, inner, dx=None):
     assert dx.is_contiguous() and dx.dtype == x.dtype
     wsb = lib.bvq_stats_workspace_bytes(STAT_ABSMAX, dt, outer, channels, inner)
     ws = torch.empty(max(int(wsb), 8), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         check(lib.bvq_stat_bwd(match, dt, ptr(x), ptr(stat), ptr(gstat), ptr(dx), outer, channels, inner,
                                mode_add, ptr(ws), ws.numel(), stream_ptr(dev)), 'bvq_stat_bwd')
     return dx
 
 
-def fakequant_fwd(desc, x, scale, zp, want_codes=False):
+def fakequant_fwd(desc, x, scale, zp, want_codes=False, want_y=True):
+    """-> y, (y, codes) or codes alone; codes have the element type of desc.codes_dtype"""
     dev = require_device(x, scale, zp)
     ct = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[desc.ct_dtype]
-    y = torch.empty(x.shape, dtype=ct, device=dev)
-    codes = torch.empty(x.shape, dtype=torch.int32, device=dev) if want_codes else None
-    with torch.cuda.device(dev):
+    y = torch.empty(x.shape, dtype=ct, device=dev) if want_y else None
+    codes = torch.empty(x.shape, dtype=_CODES_TORCH[desc.codes_dtype], device=dev) if want_codes else None
+    with _DeviceGuard(dev):
         if _timer is not None:
             _timer.before('bvq_fakequant_fwd')
         check(lib.bvq_fakequant_fwd(ctypes.byref(desc), ptr(x), ptr(scale), ptr(zp), ptr(y), ptr(codes),
                                     stream_ptr(dev)), 'bvq_fakequant_fwd')
         if _timer is not None:
             _timer.after('bvq_fakequant_fwd')
+    if not want_y:
+        return codes
     return (y, codes) if want_codes else y
 
 
@@ -276,7 +306,7 @@ def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype,
     scale = torch.empty(channels, dtype=scale_dtype, device=dev)
     wsb = lib.bvq_stats_workspace_bytes(STAT_ABSMAX, dt, outer, channels, inner)
     ws = torch.empty(max(int(wsb), 8), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         if _timer is not None:
             _timer.before('bvq_stats')
         check(lib.bvq_absmax_scale(pre_op, dt, ptr(x), outer, channels, inner, ptr(stat), float(min_val or 0.0),
@@ -297,7 +327,7 @@ def kth_value(x, k, outer, channels, inner, abs_key):
     if wsb < 0:
         raise BvqError('bvq_kth_workspace_bytes: bad arguments')
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         if _timer is not None:
             _timer.before('bvq_kth_value')
         check(lib.bvq_kth_value(int(abs_key), dt, ptr(x), outer, channels, inner, int(k), ptr(out), ptr(ws), wsb,
@@ -312,7 +342,7 @@ def running_stats_update(running, stat, momentum, first_batch):
     dev = require_device(running, stat)
     assert running.is_contiguous() and running.numel() == stat.numel()
     stat = stat.contiguous()
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         check(lib.bvq_running_stats_update(dtype_code(running.dtype), ptr(running), dtype_code(stat.dtype),
                                            ptr(stat), running.numel(), float(momentum), int(first_batch),
                                            stream_ptr(dev)), 'bvq_running_stats_update')
@@ -330,7 +360,7 @@ def stat_tie_scan(match, x, stat, outer, channels, inner, dx_zero_fill=None):
     assert x.is_contiguous()
     stat = stat.to(x.dtype).contiguous()
     info = tie_info_buffer(channels, dev)
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         check(lib.bvq_stat_tie_scan(match, dtype_code(x.dtype), ptr(x), ptr(stat), outer, channels, inner,
                                     ptr(dx_zero_fill), ptr(info), stream_ptr(dev)), 'bvq_stat_tie_scan')
     return info
@@ -342,7 +372,7 @@ def stat_tie_apply(match, x, stat, gstat, info, dx, outer, channels, inner, mode
     assert x.is_contiguous() and dx.is_contiguous() and dx.dtype == x.dtype
     stat = stat.to(x.dtype).contiguous()
     gstat = gstat.to(x.dtype).contiguous()
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         check(lib.bvq_stat_tie_apply(match, pre_op, dtype_code(x.dtype), ptr(x), ptr(stat), ptr(gstat), ptr(info),
                                      ptr(total_ties), ptr(dx), outer, channels, inner, int(mode_add),
                                      stream_ptr(dev)), 'bvq_stat_tie_apply')
@@ -355,7 +385,7 @@ def stat_tie_apply_dscale(x, stat, dscale, scale_dtype, int_threshold, quot_dtyp
     dev = require_device(x, stat, dscale, info, dx, total_ties)
     assert x.is_contiguous() and dx.is_contiguous() and dx.dtype == x.dtype and dscale.dtype == torch.float32
     stat = stat.to(x.dtype).contiguous()
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         check(lib.bvq_stat_tie_apply_dscale(pre_op, dtype_code(x.dtype), ptr(x), ptr(stat), ptr(dscale),
                                             dtype_code(scale_dtype), float(int_threshold), dtype_code(quot_dtype),
                                             ptr(info), ptr(total_ties), ptr(dx), outer, channels, inner,
@@ -382,7 +412,7 @@ def fakequant_bwd(desc, g, x, scale, zp, need_dscale, need_dzp, tie_stat=None):
         if wsb < 0:
             raise BvqError('bvq_fakequant_bwd_workspace_bytes: ' + last_error())
         ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _DeviceGuard(dev):
         if _timer is not None:
             _timer.before('bvq_fakequant_bwd')
         check(lib.bvq_fakequant_bwd(ctypes.byref(desc), ptr(g), ptr(x), ptr(scale), ptr(zp), ptr(dx), ptr(ds),

@@ -142,10 +142,17 @@ def _zero_zero_point(device):
     return z
 
 
+_AS_DTYPE = {}
+
+
 def _as_dtype_value(v: float, dtype: torch.dtype) -> float:
     """v after torch converts it to `dtype` (what a 0-dim float32 operand becomes next to a dimensioned
     tensor of that dtype on the device)"""
-    return float(torch.tensor(v, dtype=torch.float32).to(dtype))
+    key = (v, dtype)
+    r = _AS_DTYPE.get(key)
+    if r is None:
+        r = _AS_DTYPE[key] = float(torch.tensor(v, dtype=torch.float32).to(dtype))
+    return r
 
 
 class StatsFakeQuantFn(Function):

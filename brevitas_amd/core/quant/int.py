@@ -53,9 +53,24 @@ class RescalingIntQuant(torch.nn.Module):
 
     # ---- recognised graphs -----------------------------------------------------------------------------
 
-    def _stats_plan(self, x: Tensor, bit_width: Tensor):
-        """StatsPlan + the module owning a running average (or None), if a fused graph applies"""
-        if not config.FUSED_PATHS or not x.is_cuda or x.dim() == 0 or x.numel() == 0:
+    def _stats_template(self, bit_width: Tensor):
+        """Structural part of the fused-graph recognition, cached until the module graph, the training
+        flag or the configuration changes: None, or a dict describing the statistic -> scale chain."""
+        iq, sc = self.int_quant, self.scaling_impl
+        bw = getattr(bit_width, 'bvq_host_value', None)
+        key = (config.FUSED_PATHS, id(iq), id(sc), id(self.zero_point_impl), id(self.int_scaling_impl), bw,
+               getattr(sc, 'training', None), id(getattr(iq, 'float_to_int_impl', None)),
+               id(getattr(iq, 'tensor_clamp_impl', None)),
+               id(getattr(getattr(iq, 'delay_wrapper', None), 'delay_impl', None)))
+        cached = self.__dict__.get('_bvq_template')
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        tmpl = self._build_stats_template(bw)
+        self.__dict__['_bvq_template'] = (key, tmpl)
+        return tmpl
+
+    def _build_stats_template(self, bw):
+        if not config.FUSED_PATHS or bw is None:
             return None
         iq = self.int_quant
         if type(iq) is not IntQuant or not isinstance(iq.delay_wrapper.delay_impl, _NoDelay):
@@ -65,10 +80,8 @@ class RescalingIntQuant(torch.nn.Module):
             return None
         if type(self.zero_point_impl) is not ZeroZeroPoint or type(self.int_scaling_impl) is not IntScaling:
             return None
-        if getattr(bit_width, 'bvq_host_value', None) is None:
-            return None
         sc = self.scaling_impl
-        runtime = None
+        runtime, weight = None, None
         if type(sc) is RuntimeStatsScaling:
             if not sc.training:
                 return None
@@ -78,10 +91,7 @@ class RescalingIntQuant(torch.nn.Module):
             pls = sc.parameter_list_stats
             if pls.extra_tracked_params_list is not None:
                 return None
-            w = pls.first_tracked_param.parameter
-            if not (w is x or (w.data_ptr() == x.data_ptr() and w.shape == x.shape
-                               and w.stride() == x.stride() and w.dtype == x.dtype)):
-                return None
+            weight = pls.first_tracked_param.parameter
             view, stats = pls.first_tracked_param.view_shape_impl, pls.stats
         else:
             return None
@@ -89,28 +99,48 @@ class RescalingIntQuant(torch.nn.Module):
         if min_val is None or type(stats.stats_impl) is not AbsMax:
             return None
         shape = tuple(stats.stats_output_shape)
-        int_thr = self.int_scaling_impl.host_value(bit_width.bvq_host_value)
         if type(view) is OverTensorView and stats.stats_impl.stats_reduce_dim is None:
             if shape != ():
                 return None
-            return _fused.StatsPlan(1, 1, x.numel(), shape, min_val, int_thr), runtime
-        if type(view) is OverOutputChannelView and stats.stats_impl.stats_reduce_dim in (1, -1):
-            cd = view.bvq_channel_dim(x.dim())
-            if cd is None or cd < 0:
-                return None
-            # the scaling shape must broadcast against x exactly at the channel dim
-            want = tuple(x.shape[cd] if i == cd else 1 for i in range(x.dim()))
-            padded = (1,) * (x.dim() - len(shape)) + shape
-            if len(shape) > x.dim() or padded != want or x.shape[cd] == 1:
-                return None
-            outer = 1
-            for s in x.shape[:cd]:
-                outer *= s
-            inner = 1
-            for s in x.shape[cd + 1:]:
-                inner *= s
-            return _fused.StatsPlan(outer, x.shape[cd], inner, shape, min_val, int_thr), runtime
-        return None
+            per_channel = False
+        elif type(view) is OverOutputChannelView and stats.stats_impl.stats_reduce_dim in (1, -1):
+            per_channel = True
+        else:
+            return None
+        qmin, qmax = int_range_host(iq.signed, iq.narrow_range, bw)
+        return dict(runtime=runtime, weight=weight, view=view, shape=shape, min_val=min_val,
+                    per_channel=per_channel, int_thr=self.int_scaling_impl.host_value(bw), qmin=qmin, qmax=qmax,
+                    round_mode=iq.float_to_int_impl.bvq_round_mode, clamp_ste=iq.tensor_clamp_impl.bvq_clamp_ste)
+
+    def _stats_plan(self, x: Tensor, bit_width: Tensor):
+        """(StatsPlan, template) if a recognised fused graph applies to this input, else None"""
+        if not x.is_cuda or x.dim() == 0 or x.numel() == 0:
+            return None
+        tmpl = self._stats_template(bit_width)
+        if tmpl is None:
+            return None
+        w = tmpl['weight']
+        if w is not None and not (w is x or (w.data_ptr() == x.data_ptr() and w.shape == x.shape
+                                             and w.stride() == x.stride() and w.dtype == x.dtype)):
+            return None  # the statistic is taken of another tensor than the one being quantized
+        shape = tmpl['shape']
+        if not tmpl['per_channel']:
+            return _fused.StatsPlan(1, 1, x.numel(), shape, tmpl['min_val'], tmpl['int_thr']), tmpl
+        cd = tmpl['view'].bvq_channel_dim(x.dim())
+        if cd is None or cd < 0:
+            return None
+        # the scaling shape must broadcast against x exactly at the channel dim
+        want = tuple(x.shape[cd] if i == cd else 1 for i in range(x.dim()))
+        padded = (1,) * (x.dim() - len(shape)) + shape
+        if len(shape) > x.dim() or padded != want or x.shape[cd] == 1:
+            return None
+        outer = 1
+        for d in x.shape[:cd]:
+            outer *= d
+        inner = 1
+        for d in x.shape[cd + 1:]:
+            inner *= d
+        return _fused.StatsPlan(outer, x.shape[cd], inner, shape, tmpl['min_val'], tmpl['int_thr']), tmpl
 
     def forward(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
         return self.bvq_forward_pre(x, nat.PRE_NONE)
@@ -144,15 +174,14 @@ class RescalingIntQuant(torch.nn.Module):
             x = torch.relu(x)  # not fusable here: materialise the activation like the reference does
             pre_op = nat.PRE_NONE
         if fused is not None:
-            sp, runtime = fused
-            iq = self.int_quant
+            sp, tmpl = fused
+            runtime = tmpl['runtime']
             int_threshold = self.int_scaling_impl(bit_width)
-            qmin, qmax = int_range_host(iq.signed, iq.narrow_range, bit_width.bvq_host_value)
             # a batch-sharded activation (brevitas_amd.distributed.shard_over_batch); weights are replicated
             group = getattr(self, 'bvq_shard_group', None) if runtime is not None else None
             y, scale, stat = _fused.StatsFakeQuantFn.apply(
-                x, int_threshold, sp, qmin, qmax, iq.float_to_int_impl.bvq_round_mode,
-                iq.tensor_clamp_impl.bvq_clamp_ste, group, pre_op)
+                x, int_threshold, sp, tmpl['qmin'], tmpl['qmax'], tmpl['round_mode'], tmpl['clamp_ste'], group,
+                pre_op)
             if runtime is not None:
                 runtime.update_running_stats(stat)
             zero_point = self.zero_point_impl(x, scale, bit_width)

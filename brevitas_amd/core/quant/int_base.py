@@ -79,6 +79,30 @@ class IntQuant(torch.nn.Module):
         y = self.tensor_clamp_impl(y, min_val=min_int_val, max_val=max_int_val)
         return y
 
+    def to_int_codes(self, scale: Tensor, zero_point: Tensor, bit_width: Tensor, x: Tensor) -> Tensor:
+        """to_int as an INTEGER tensor, in the dtype QuantTensor.int() uses (B/quant_tensor/__init__.py:
+        174-187): int8 / uint8 up to 8 bits, int32 above.  One read of x and one 1-byte (4-byte) write per
+        element -- the operand layout of integer GEMMs and of the QCDQ exporters
+        (B/export/common/handler/qcdq.py:47-90).  Not differentiable."""
+        bw = getattr(bit_width, 'bvq_host_value', None)
+        if bw is None:
+            bw = int(bit_width.item())
+        if bw <= 8:
+            tdt, cdt = (torch.int8, nat.CODES_I8) if self.signed else (torch.uint8, nat.CODES_U8)
+        else:
+            tdt, cdt = torch.int32, nat.CODES_I32
+        fa = self._fused_args(scale, zero_point, bit_width, x)
+        if fa is None:
+            with torch.no_grad():
+                return self.to_int(scale, zero_point, bit_width, x).to(tdt)
+        p, qmin, qmax, round_mode, clamp_ste = fa
+        xc = x.detach().contiguous()
+        sc = scale.detach().reshape(-1).contiguous()
+        zc = zero_point.detach().reshape(-1).contiguous()
+        desc = _fused.make_desc(p, xc, sc, zc, qmin, qmax, round_mode, clamp_ste, nat.OUT_INT)
+        desc.codes_dtype = cdt
+        return nat.fakequant_fwd(desc, xc, sc, zc, want_codes=True, want_y=False)
+
     def min_int(self, bit_width):
         return min_int(self.signed, self.narrow_range, bit_width)
 

@@ -17,7 +17,7 @@ struct QuantArgs {
   const void* scale;
   const void* zp;
   void* y;          // fwd: output; bwd: dx
-  int32_t* codes;   // fwd only, nullable
+  void* codes;      // fwd only, nullable; element type codes_dtype
   const void* g;    // bwd only
   float* ds_part;   // bwd only, per-unit partial of dscale
   float* dzp_part;  // bwd only, per-unit partial of dzp
@@ -31,6 +31,7 @@ struct QuantArgs {
   int32_t out_int;
   int32_t round_mode;
   int32_t pre_relu;  // x is passed through torch.relu first (FusedActivationQuantProxy)
+  int32_t codes_dtype;
 };
 
 #ifndef BVQ_FWD_UNROLL
@@ -112,13 +113,34 @@ __device__ __forceinline__ float fwd_elem(float xf, const Div& div, float s, flo
   return ZP0 ? rnd<CT>(q * s) : rnd<CT>(rnd<CT>(q - z) * s);  // (y_int - zero_point) * scale :93-94
 }
 
+// store VEC integer codes (parity / export mode): int32, int8 or uint8
+template <int VEC>
+__device__ __forceinline__ void store_codes(void* base, int codes_dtype, int64_t off, const float* q) {
+  if (codes_dtype == BVQ_CODES_I32) {
+    vec_t<int32_t, VEC> cv;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) cv.v[k] = (int32_t)q[k];
+    store_vec<int32_t, VEC>(reinterpret_cast<int32_t*>(base) + off, cv);
+  } else if (codes_dtype == BVQ_CODES_I8) {
+    vec_t<int8_t, VEC> cv;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) cv.v[k] = (int8_t)(int32_t)q[k];
+    store_vec<int8_t, VEC>(reinterpret_cast<int8_t*>(base) + off, cv);
+  } else {
+    vec_t<uint8_t, VEC> cv;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) cv.v[k] = (uint8_t)(int32_t)q[k];
+    store_vec<uint8_t, VEC>(reinterpret_cast<uint8_t*>(base) + off, cv);
+  }
+}
+
 template <typename XT, typename CT, int VEC, int RM, bool NT, bool ZP0, bool PRE, typename Div>
 __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, const Div& div, float s,
                                          float z, float qmin, float qmax) {
   const int lane = threadIdx.x & 63;
   const XT* __restrict__ xp = reinterpret_cast<const XT*>(a.x) + u.base;
-  CT* __restrict__ yp = reinterpret_cast<CT*>(a.y) + u.base;
-  int32_t* __restrict__ cp = a.codes ? a.codes + u.base : nullptr;
+  CT* __restrict__ yp = a.y ? reinterpret_cast<CT*>(a.y) + u.base : nullptr;
+  void* const cp = a.codes;  // indexed from the tensor start: u.base + offset
   const bool out_int = a.out_int != 0;
   const int mode = a.round_mode;
 
@@ -147,13 +169,8 @@ __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, cons
           const float r = fwd_elem<CT, RM, ZP0>(xf, div, s, z, qmin, qmax, out_int, mode, qv[k]);
           yv.v[k] = from_f<CT>(r);
         }
-        store_vec<CT, VEC, NT>(yp + off[j], yv);
-        if (cp) {  // parity / export mode only
-          vec_t<int32_t, VEC> cv;
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) cv.v[k] = (int32_t)qv[k];
-          store_vec<int32_t, VEC>(cp + off[j], cv);
-        }
+        if (yp) store_vec<CT, VEC, NT>(yp + off[j], yv);
+        if (cp) store_codes<VEC>(cp, a.codes_dtype, u.base + off[j], qv);  // parity / export mode only
       }
     }
   }
@@ -163,8 +180,8 @@ __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, cons
     float q;
     const float xf = PRE ? relu_f(to_f<XT>(xp[i])) : to_f<XT>(xp[i]);
     const float r = fwd_elem<CT, RM, ZP0>(xf, div, s, z, qmin, qmax, out_int, mode, q);
-    yp[i] = from_f<CT>(r);
-    if (cp) cp[i] = (int32_t)q;
+    if (yp) yp[i] = from_f<CT>(r);
+    if (cp) store_codes<1>(cp, a.codes_dtype, u.base + i, &q);
   }
 }
 
@@ -395,6 +412,10 @@ static int validate(const bvq_quant_desc* d) {
     set_error("bad pre_op %d", d->pre_op);
     return BVQ_ERR_INVALID;
   }
+  if (d->codes_dtype < BVQ_CODES_I32 || d->codes_dtype > BVQ_CODES_U8) {
+    set_error("bad codes_dtype %d", d->codes_dtype);
+    return BVQ_ERR_INVALID;
+  }
   if (d->round_mode < BVQ_ROUND || d->round_mode > BVQ_DPU_ROUND) {
     set_error("bad round_mode %d", d->round_mode);
     return BVQ_ERR_INVALID;
@@ -439,6 +460,7 @@ static void fill_args(QuantArgs& a, const bvq_quant_desc* d) {
   a.out_int = d->out_kind == BVQ_OUT_INT;
   a.round_mode = d->round_mode;
   a.pre_relu = d->pre_op == BVQ_PRE_RELU;
+  a.codes_dtype = d->codes_dtype;
 }
 
 // instantiated vector widths: 16 bytes of x per lane, or one element (ragged / misaligned rows)
@@ -533,12 +555,12 @@ using namespace bvq;
 
 #if BVQ_PART == 0 || BVQ_PART == 1
 extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const void* scale,
-                                 const void* zp, void* y, int32_t* codes, bvq_stream_t stream) {
+                                 const void* zp, void* y, void* codes, bvq_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
   const int64_t n = d->outer * d->channels * d->inner;
   if (n == 0) return BVQ_OK;
-  if (!x || !scale || !zp || !y) {
+  if (!x || !scale || !zp || (!y && !codes)) {
     set_error("bvq_fakequant_fwd: null pointer");
     return BVQ_ERR_INVALID;
   }
@@ -546,7 +568,7 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
   int32_t channels;
   rows_of(d, outer, row_len, channels);
   const void* ptrs[3] = {x, y, codes};
-  const int els[3] = {dtype_size(d->x_dtype), dtype_size(d->ct_dtype), 4};
+  const int els[3] = {dtype_size(d->x_dtype), dtype_size(d->ct_dtype), d->codes_dtype == BVQ_CODES_I32 ? 4 : 1};
   const int full = 16 / dtype_size(d->x_dtype);
   const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3), full);
   QuantArgs a = {};

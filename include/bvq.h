@@ -89,6 +89,11 @@ typedef enum bvq_scalar_mode { BVQ_SCALAR_OPMATH = 0, BVQ_SCALAR_CAST = 1 } bvq_
  * grad * (x > 0) (threshold_backward). */
 typedef enum bvq_pre_op { BVQ_PRE_NONE = 0, BVQ_PRE_RELU = 1 } bvq_pre_op;
 
+/* element type of the integer codes bvq_fakequant_fwd can emit: what QuantTensor.int() returns
+ * (B/quant_tensor/__init__.py:174-187: int8 / uint8 up to 8 bits, int32 above) and what the QCDQ export
+ * handlers quantize to (B/export/common/handler/qcdq.py:71-84) */
+typedef enum bvq_codes_dtype { BVQ_CODES_I32 = 0, BVQ_CODES_I8 = 1, BVQ_CODES_U8 = 2 } bvq_codes_dtype;
+
 /* output selection for bvq_fakequant_fwd */
 #define BVQ_OUT_DEQUANT 0 /* y = (clamp(round(x/s+zp)) - zp) * s   IntQuant.forward, B/core/quant/int_base.py:86-97 */
 #define BVQ_OUT_INT 1     /* y =  clamp(round(x/s+zp))             IntQuant.to_int,  B/core/quant/int_base.py:63-76 */
@@ -118,6 +123,7 @@ typedef struct bvq_quant_desc {
                           0: TensorClamp (grad masked where clipped, activations). B/core/quant/int_base.py:53-54 */
   int32_t out_kind;    /* forward only. BVQ_OUT_DEQUANT or BVQ_OUT_INT */
   int32_t pre_op;      /* bvq_pre_op applied to x first (forward and backward) */
+  int32_t codes_dtype; /* forward only: element type of the optional integer-code output (bvq_codes_dtype) */
 } bvq_quant_desc;
 
 /* ---- library ------------------------------------------------------------------------------ */
@@ -261,10 +267,11 @@ int bvq_stat_tie_apply_dscale(int pre_op, int dtype, const void* x, const void* 
  *   t = x / scale ; t = t + zp ; t = round_mode(t) ; t = clamp(t, qmin, qmax) ;
  *   y = (t - zp) * scale          (BVQ_OUT_DEQUANT)   or   y = t   (BVQ_OUT_INT)
  * with every operation rounded to ct_dtype exactly where the reference's op chain rounds
- * (B/core/quant/int_base.py:63-97).  codes (nullable, int32, same element count) receives the
- * clamped integer codes. */
+ * (B/core/quant/int_base.py:63-97).  codes (nullable, desc->codes_dtype, same element count) receives
+ * the clamped integer codes; y may be null when only the codes are wanted (1 read of x, 1-4 bytes
+ * written per element: the layout downstream integer kernels and the QCDQ exporters consume). */
 int bvq_fakequant_fwd(const bvq_quant_desc* desc, const void* x, const void* scale, const void* zp,
-                      void* y, int32_t* codes, bvq_stream_t stream);
+                      void* y, void* codes, bvq_stream_t stream);
 
 /* bytes of scratch bvq_fakequant_bwd needs */
 int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* desc);

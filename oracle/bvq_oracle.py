@@ -30,7 +30,7 @@ class QuantDesc(ctypes.Structure):
         ('zp_dtype', ctypes.c_int32), ('scale_per_channel', ctypes.c_int32),
         ('zp_per_channel', ctypes.c_int32), ('qmin', ctypes.c_float), ('qmax', ctypes.c_float),
         ('round_mode', ctypes.c_int32), ('scalar_mode', ctypes.c_int32), ('clamp_ste', ctypes.c_int32),
-        ('out_kind', ctypes.c_int32), ('pre_op', ctypes.c_int32)]
+        ('out_kind', ctypes.c_int32), ('pre_op', ctypes.c_int32), ('codes_dtype', ctypes.c_int32)]
 
 
 def build(force=False):

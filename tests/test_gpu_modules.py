@@ -321,3 +321,28 @@ def test_int_quant_module_golden(c, fused, monkeypatch):
     assert_dx(x.grad, c, x)
     assert scale.grad is not None and scale.grad.shape == scale.shape and scale.grad.dtype == scale.dtype
     assert zp.grad is not None and zp.grad.shape == zp.shape
+
+
+@pytest.mark.parametrize('c', INT_QUANT, ids=G.ids(INT_QUANT, ['x_dtype', 'layout', 'round', 'clamp', 'bit_width']))
+def test_int_codes_emission(c):
+    """integer codes in QuantTensor.int()'s dtype (int8 signed / uint8 unsigned up to 8 bits), written
+    directly by the quantizer kernel: equal to the reference's to_int cast to that dtype"""
+    from brevitas_amd.core.function_wrapper import (CeilSte, DPURoundSte, FloorSte, RoundSte, RoundToZeroSte,
+                                                    TensorClamp, TensorClampSte)
+    m = mods()
+    rimpl = {'round': RoundSte, 'floor': FloorSte, 'ceil': CeilSte, 'rtz': RoundToZeroSte, 'dpu': DPURoundSte}
+    iq = m['IntQuant'](narrow_range=c['narrow'], signed=c['signed'], float_to_int_impl=rimpl[c['round']](),
+                       tensor_clamp_impl=TensorClampSte() if c['clamp'] == 'ste' else TensorClamp()).to(DEV)
+    bw = m['BitWidthConst'](c['bit_width']).to(DEV)()
+    x, scale, zp = c.torch('x', DEV), c.torch('scale', DEV), c.torch('zp', DEV)
+    codes = iq.to_int_codes(scale, zp, bw, x)
+    assert codes.dtype == (torch.int8 if c['signed'] else torch.uint8) and codes.shape == x.shape
+    want = c.f32('y_int').reshape(x.shape)
+    fin = np.isfinite(want)
+    got = codes.cpu().numpy().astype(np.int64)
+    assert np.array_equal(got[fin], want[fin].astype(np.int64))
+    # the same through a plain tensor bit width (op-by-op route + cast)
+    codes2 = iq.to_int_codes(scale, zp, torch.tensor(float(c['bit_width']), device=DEV), x)
+    assert codes2.dtype == codes.dtype
+    if not (c.arr('scale').size == 1 and c['dtypes']['scale'] == 'f32' and c['dtypes']['x'] != 'f32'):
+        assert np.array_equal(codes2.cpu().numpy()[fin], codes.cpu().numpy()[fin])

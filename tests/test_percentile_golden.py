@@ -74,11 +74,12 @@ def test_gpu_abs_percentile(c):
         out.backward(gout)
         dx = x.grad.float().cpu().reshape(x.shape)
         want = c.f32('dx').reshape(x.shape)
-        # one element per selected value receives sgn(x) * gout: same row sums as the reference; which of
-        # several equal elements gets it is implementation-defined in torch
+        # one element per selected value receives sgn(x) * gout.  Which of several elements with the same
+        # |x| gets it is implementation-defined in torch (and +a / -a ties flip the sign), so compare the
+        # magnitude of the row sums with the reference and check where the gradient sits.
         rows = dx.reshape(1, -1) if c['dim'] is None else dx
         wrows = torch.from_numpy(want).reshape(rows.shape)
-        assert torch.equal(rows.sum(dim=1), wrows.sum(dim=1))
+        assert torch.equal(rows.sum(dim=1).abs(), wrows.sum(dim=1).abs())
         assert int((rows != 0).sum(dim=1).max()) <= 1
         nz = rows != 0
         xa = x.detach().float().cpu().abs().reshape(rows.shape)
