@@ -24,7 +24,10 @@
 namespace bvq {
 
 constexpr int kWave = 64;
-constexpr int kBlock = 256;
+#ifndef BVQ_BLOCK
+#define BVQ_BLOCK 256
+#endif
+constexpr int kBlock = BVQ_BLOCK;
 constexpr int kWavesPerBlock = kBlock / kWave;
 
 // ---- error reporting ---------------------------------------------------------------------------
@@ -119,6 +122,20 @@ __device__ __forceinline__ vec_t<T, N> load_vec(const T* p) {
 }
 template <typename T, int N, bool NT = false>
 __device__ __forceinline__ void store_vec(T* p, const vec_t<T, N>& v) {
+#ifdef BVQ_STORE_ASM  // build-time experiment: explicit cache-policy bits on the streaming store
+  if constexpr (NT && sizeof(T) * N == 16) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 d = __builtin_bit_cast(u32x4, v);
+#if BVQ_STORE_ASM == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+#elif BVQ_STORE_ASM == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(d) : "memory");
+#endif
+    return;
+  }
+#endif
   if constexpr (NT && sizeof(T) * N == 16) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
