@@ -1,3 +1,6 @@
+from .binary import BinaryQuant, ClampedBinaryQuant
 from .delay import DelayWrapper
-from .int import PrescaledRestrictIntQuant, PrescaledRestrictIntQuantWithInputBitWidth, RescalingIntQuant
-from .int_base import IntQuant
+from .int import (DecoupledRescalingIntQuant, PrescaledRestrictIntQuant, PrescaledRestrictIntQuantWithInputBitWidth,
+                  RescalingIntQuant, TruncIntQuant)
+from .int_base import DecoupledIntQuant, IntQuant
+from .ternary import TernaryQuant

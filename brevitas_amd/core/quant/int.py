@@ -236,3 +236,59 @@ class PrescaledRestrictIntQuant(torch.nn.Module):
         zero_point = self.zero_point()
         y = self.int_quant(scale, zero_point, msb_clamp_bit_width, x)
         return y, scale, zero_point, msb_clamp_bit_width
+
+
+class DecoupledRescalingIntQuant(torch.nn.Module):
+    """DecoupledIntQuant with scales / zero-points from sub-modules (drop-in for B/core/quant/int.py:166-196);
+    returns (y, scale, zero_point, bit_width, pre_scale, pre_zero_point)"""
+
+    def __init__(self, decoupled_int_quant: Module, pre_scaling_impl: Module, scaling_impl: Module,
+                 int_scaling_impl: Module, pre_zero_point_impl: Module, zero_point_impl: Module, bit_width_impl: Module):
+        super().__init__()
+        self.decoupled_int_quant = decoupled_int_quant
+        self.pre_scaling_impl = pre_scaling_impl
+        self.scaling_impl = scaling_impl
+        self.int_scaling_impl = int_scaling_impl
+        self.pre_zero_point_impl = pre_zero_point_impl
+        self.zero_point_impl = zero_point_impl
+        self.msb_clamp_bit_width_impl = bit_width_impl
+
+    def forward(self, x: Tensor):
+        bit_width = self.msb_clamp_bit_width_impl()
+        int_threshold = self.int_scaling_impl(bit_width)
+        pre_threshold = self.pre_scaling_impl(x)
+        pre_scale = pre_threshold / int_threshold
+        pre_zero_point = self.pre_zero_point_impl(x, pre_scale, bit_width)
+        threshold = self.scaling_impl(x)
+        scale = threshold / int_threshold
+        zero_point = self.zero_point_impl(x, scale, bit_width)
+        y = self.decoupled_int_quant(pre_scale, pre_zero_point, scale, zero_point, bit_width, x)
+        return y, scale, zero_point, bit_width, pre_scale, pre_zero_point
+
+
+class TruncIntQuant(torch.nn.Module):
+    """Truncation of an already quantized value to fewer bits (drop-in for B/core/quant/int.py:199-229):
+    recover the integer, drop `input_bit_width - output_bit_width` LSBs with float_to_int_impl, de-quantize"""
+
+    def __init__(self, float_to_int_impl: Module, bit_width_impl: Module, quant_delay_steps: int = 0):
+        super().__init__()
+        from brevitas_amd.core.quant.delay import DelayWrapper
+        self.msb_clamp_bit_width_impl = bit_width_impl
+        self.float_to_int_impl = float_to_int_impl
+        self.delay_wrapper = DelayWrapper(quant_delay_steps)
+
+    def forward(self, x: Tensor, scale: Tensor, zero_point: Tensor, input_bit_width: Tensor
+                ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+        from brevitas_amd.function.ops_ste import round_ste
+        y = x / scale
+        y = y + zero_point
+        y = round_ste(y)  # clean up floating point error
+        output_bit_width = self.msb_clamp_bit_width_impl()
+        trunc_bit_width = input_bit_width - output_bit_width
+        trunc_scale = 2.0 ** trunc_bit_width
+        y = y / trunc_scale
+        y = self.float_to_int_impl(y)
+        y = y - zero_point
+        y = y * scale
+        y = self.delay_wrapper(x, y)
+        return y, scale, zero_point, output_bit_width

@@ -130,3 +130,45 @@ class IntQuant(torch.nn.Module):
             y = y_int - zero_point
             y = y * scale
         return self.delay_wrapper(x_act, y)
+
+
+class DecoupledIntQuant(torch.nn.Module):
+    """Integer quantizer whose rounding uses (pre_scale, pre_zero_point) and whose de-quantization uses
+    (scale, zero_point) (drop-in for B/core/quant/int_base.py:100-182).
+
+    Examples (B/core/quant/int_base.py:118-126):
+        >>> q = DecoupledIntQuant(narrow_range=True, signed=True)
+        >>> q(torch.tensor(0.02), torch.tensor(0.), torch.tensor(0.01), torch.tensor(0.), torch.tensor(4.), inp)
+        tensor([ 0.0200, -0.0300,  0.0700, -0.0700])
+    """
+
+    def __init__(self, narrow_range: bool, signed: bool, float_to_int_impl: Module = RoundSte(),
+                 tensor_clamp_impl: Module = TensorClamp(), quant_delay_steps: int = 0):
+        super().__init__()
+        self.float_to_int_impl = float_to_int_impl
+        self.tensor_clamp_impl = tensor_clamp_impl
+        self.signed = signed
+        self.narrow_range = narrow_range
+        self.delay_wrapper = DelayWrapper(quant_delay_steps)
+
+    def to_int(self, pre_scale: Tensor, pre_zero_point: Tensor, bit_width: Tensor, x: Tensor) -> Tensor:
+        y = x / pre_scale
+        y = y + pre_zero_point
+        min_int_val = self.min_int(bit_width)
+        max_int_val = self.max_int(bit_width)
+        y = self.float_to_int_impl(y)
+        y = self.tensor_clamp_impl(y, min_val=min_int_val, max_val=max_int_val)
+        return y
+
+    def min_int(self, bit_width):
+        return min_int(self.signed, self.narrow_range, bit_width)
+
+    def max_int(self, bit_width):
+        return max_int(self.signed, self.narrow_range, bit_width)
+
+    def forward(self, pre_scale: Tensor, pre_zero_point: Tensor, scale: Tensor, zero_point: Tensor, bit_width: Tensor,
+                x: Tensor) -> Tensor:
+        y_int = self.to_int(pre_scale, pre_zero_point, bit_width, x)
+        y = y_int - zero_point
+        y = y * scale
+        return self.delay_wrapper(x, y)

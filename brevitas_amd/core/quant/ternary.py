@@ -1,0 +1,37 @@
+"""Ternary quantizer (drop-in for B/core/quant/ternary.py:15-66)."""
+from typing import Tuple
+
+import torch
+from torch import Tensor
+from torch.nn import Module
+
+from brevitas_amd.core.bit_width import BitWidthConst
+from brevitas_amd.core.quant.delay import DelayWrapper
+from brevitas_amd.core.utils import StatelessBuffer
+from brevitas_amd.function.ops_ste import ternary_sign_ste
+
+
+class TernaryQuant(torch.nn.Module):
+    """y = [|x| > threshold * scale] * ternary_sign_ste(x) * scale; bit width 2, zero-point 0
+
+    Examples (B/core/quant/ternary.py:32-44):
+        >>> out, scale, zero_point, bit_width = TernaryQuant(ConstScaling(1.0), 0.5)(torch.Tensor([0.04, -0.6, 3.3]))
+        >>> out
+        tensor([ 0., -1.,  1.])
+    """
+
+    def __init__(self, scaling_impl: Module, threshold: float, quant_delay_steps: int = None):
+        super().__init__()
+        self.scaling_impl = scaling_impl
+        self.threshold = threshold
+        self.bit_width = BitWidthConst(2)
+        self.zero_point = StatelessBuffer(torch.tensor(0.0))
+        self.delay_wrapper = DelayWrapper(quant_delay_steps)
+
+    def forward(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+        scale = self.scaling_impl(x)
+        mask = x.abs().gt(self.threshold * scale)
+        y = mask.float() * ternary_sign_ste(x)
+        y = y * scale
+        y = self.delay_wrapper(x, y)
+        return y, scale, self.zero_point(), self.bit_width()

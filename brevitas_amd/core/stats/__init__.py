@@ -1,3 +1,4 @@
-from .stats_op import AbsMax, AbsMinMax, AbsPercentile, NegativePercentileOrZero, PercentileInterval
+from .stats_op import (AbsMax, AbsMinMax, AbsPercentile, NegativeMinOrZero, NegativePercentileOrZero,
+                       PercentileInterval)
 from .stats_wrapper import DEFAULT_MOMENTUM, SCALAR_SHAPE, _ParameterListStats, _RuntimeStats, _Stats
 from .view_wrapper import _ViewCatParameterWrapper, _ViewParameterWrapper

@@ -172,6 +172,20 @@ class PercentileInterval(torch.nn.Module):
         return torch.abs(high_result - low_result)
 
 
+class NegativeMinOrZero(torch.nn.Module):
+    """min(min(x), 0) over the whole input or along `stats_reduce_dim` (B/core/stats/stats_op.py:21-38): the
+    (negated) offset of asymmetric quantizers.  One streaming read by the min/max reduction."""
+
+    def __init__(self, stats_reduce_dim: Optional[int] = None) -> None:
+        super().__init__()
+        self.stats_reduce_dim = stats_reduce_dim
+
+    def forward(self, x: Tensor) -> Tensor:
+        _, min_val = _MinMaxFn.apply(x, self.stats_reduce_dim)
+        zero = torch.zeros((), dtype=min_val.dtype, device=min_val.device)
+        return torch.where(min_val <= zero, min_val, zero)
+
+
 class AbsMax(torch.nn.Module):
     """max(|x|) over the whole (1-D) input, or along `stats_reduce_dim` of a [C, K] view"""
 

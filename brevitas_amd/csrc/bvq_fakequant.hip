@@ -67,7 +67,7 @@ __device__ __forceinline__ float do_round(float t, int mode) {
 // division by the (wave-uniform) scale
 // ------------------------------------------------------------------------------------------------
 // DivExact: IEEE division, always right.
-// DivBf16 : a * (1/s) for a bf16 quotient of bf16 operands.  The reference computes
+// DivBf16 : a * (1/s) for a bf16 quotient of bf16 operands (any zero-point).  The reference computes
 //           RN_bf16(RN_f32(a / s)).  With a and s both bf16 values (8-bit significands) the exact
 //           quotient is never closer than 2^-17 (relative) to a bf16 rounding boundary and never ON
 //           one (a = m*s with m a 9-bit odd-ended midpoint needs >= 9 significant bits), while
@@ -83,11 +83,12 @@ struct DivBf16 {
   __device__ __forceinline__ float operator()(float a) const { return a * r; }
 };
 
-__device__ __forceinline__ bool bf16_fast_ok(float s, float z) {
+__device__ __forceinline__ bool bf16_scale_ok(float s) {
   const uint32_t sb = __builtin_bit_cast(uint32_t, s);
-  return (sb & 0xffffu) == 0u && s >= 6.103515625e-05f && s <= 16384.f &&
-         __builtin_bit_cast(uint32_t, z) == 0u;
+  return (sb & 0xffffu) == 0u && s >= 6.103515625e-05f && s <= 16384.f;
 }
+// the zero-point is exactly +0.0 (symmetric quantizers): see ZP0 below
+__device__ __forceinline__ bool zp_is_pos_zero(float z) { return __builtin_bit_cast(uint32_t, z) == 0u; }
 
 // This file is compiled twice (brevitas_amd/csrc/build.py): BVQ_PART=1 holds the forward kernels and
 // entry point, BVQ_PART=2 the backward ones -- two translation units build in parallel.
@@ -193,20 +194,37 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
   load_scale_zp<CT>(a, u.channel, s, z);
   // the reference clamps against min_int/max_int converted to the tensor dtype (max_val.type_as(x))
   const float qmin = rnd<CT>(a.qmin), qmax = rnd<CT>(a.qmax);
-  // wave-uniform choices: fused pre-activation, and (bf16) the reciprocal fast path
+  // wave-uniform choices: fused pre-activation, zero zero-point (16-bit compute types: saves two
+  // re-roundings per element), and (bf16) the reciprocal fast path
+  const bool zp0 = sizeof(CT) == 2 && zp_is_pos_zero(z);
+#define BVQ_FWD_UNIT(ZP0, PRE, DIV) fwd_unit<XT, CT, VEC, RM, NT, ZP0, PRE>(a, u, DIV, s, z, qmin, qmax)
+#define BVQ_FWD_PRE(ZP0, DIV)      \
+  do {                             \
+    if (a.pre_relu)                \
+      BVQ_FWD_UNIT(ZP0, true, DIV); \
+    else                           \
+      BVQ_FWD_UNIT(ZP0, false, DIV); \
+  } while (0)
   if constexpr (elem<CT>::id == BVQ_BF16) {
-    if (bf16_fast_ok(s, z)) {
-      if (a.pre_relu)
-        fwd_unit<XT, CT, VEC, RM, NT, true, true>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
+    if (bf16_scale_ok(s)) {
+      const DivBf16 div{1.0f / s};
+      if (zp0)
+        BVQ_FWD_PRE(true, div);
       else
-        fwd_unit<XT, CT, VEC, RM, NT, true, false>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
+        BVQ_FWD_PRE(false, div);
       return;
     }
   }
-  if (a.pre_relu)
-    fwd_unit<XT, CT, VEC, RM, NT, false, true>(a, u, DivExact{s}, s, z, qmin, qmax);
-  else
-    fwd_unit<XT, CT, VEC, RM, NT, false, false>(a, u, DivExact{s}, s, z, qmin, qmax);
+  const DivExact div{s};
+  if constexpr (sizeof(CT) == 2) {
+    if (zp0) {
+      BVQ_FWD_PRE(true, div);
+      return;
+    }
+  }
+  BVQ_FWD_PRE(false, div);
+#undef BVQ_FWD_PRE
+#undef BVQ_FWD_UNIT
 }
 
 #endif  // forward part
@@ -345,19 +363,35 @@ __global__ __launch_bounds__(kBlock) void fakequant_bwd_kernel(QuantArgs a) {
   float s, z;
   load_scale_zp<CT>(a, u.channel, s, z);
   const float qmin = rnd<CT>(a.qmin), qmax = rnd<CT>(a.qmax);
+  const bool zp0 = sizeof(CT) == 2 && zp_is_pos_zero(z);
+#define BVQ_BWD_UNIT(ZP0, PRE, DIV) bwd_unit<XT, CT, VEC, RM, MODE, NT, ZP0, PRE>(a, u, DIV, s, z, qmin, qmax)
+#define BVQ_BWD_PRE(ZP0, DIV)      \
+  do {                             \
+    if (a.pre_relu)                \
+      BVQ_BWD_UNIT(ZP0, true, DIV); \
+    else                           \
+      BVQ_BWD_UNIT(ZP0, false, DIV); \
+  } while (0)
   if constexpr (elem<CT>::id == BVQ_BF16) {
-    if (bf16_fast_ok(s, z)) {
-      if (a.pre_relu)
-        bwd_unit<XT, CT, VEC, RM, MODE, NT, true, true>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
+    if (bf16_scale_ok(s)) {
+      const DivBf16 div{1.0f / s};
+      if (zp0)
+        BVQ_BWD_PRE(true, div);
       else
-        bwd_unit<XT, CT, VEC, RM, MODE, NT, true, false>(a, u, DivBf16{1.0f / s}, s, z, qmin, qmax);
+        BVQ_BWD_PRE(false, div);
       return;
     }
   }
-  if (a.pre_relu)
-    bwd_unit<XT, CT, VEC, RM, MODE, NT, false, true>(a, u, DivExact{s}, s, z, qmin, qmax);
-  else
-    bwd_unit<XT, CT, VEC, RM, MODE, NT, false, false>(a, u, DivExact{s}, s, z, qmin, qmax);
+  const DivExact div{s};
+  if constexpr (sizeof(CT) == 2) {
+    if (zp0) {
+      BVQ_BWD_PRE(true, div);
+      return;
+    }
+  }
+  BVQ_BWD_PRE(false, div);
+#undef BVQ_BWD_PRE
+#undef BVQ_BWD_UNIT
 }
 
 // Combine per-unit partial sums of one channel in a fixed order (double accumulation):

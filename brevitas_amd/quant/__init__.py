@@ -17,11 +17,13 @@ from brevitas_amd.core.quant import IntQuant, RescalingIntQuant
 from brevitas_amd.core.restrict_val import FloatRestrictValue
 from brevitas_amd.core.scaling import (IntScaling, ParameterFromRuntimeStatsScaling, ParameterScaling,
                                        RuntimeStatsScaling, StatsFromParameterScaling)
-from brevitas_amd.core.stats import AbsMax
-from brevitas_amd.core.zero_point import ZeroZeroPoint
+from brevitas_amd.core.stats import (AbsMax, AbsMinMax, AbsPercentile, NegativeMinOrZero, NegativePercentileOrZero,
+                                     PercentileInterval)
+from brevitas_amd.core.zero_point import ParameterFromRuntimeZeroPoint, StatsFromParameterZeroPoint, ZeroZeroPoint
 
 __all__ = ['Int8WeightPerChannelFloat', 'Int4WeightPerChannelFloat', 'Int8WeightPerTensorFloat',
-           'Int8ActPerTensorFloat', 'Uint8ActPerTensorFloat', 'Int8ActPerChannelFloat']
+           'Int8ActPerTensorFloat', 'Uint8ActPerTensorFloat', 'Int8ActPerChannelFloat',
+           'ShiftedUint8WeightPerTensorFloat', 'ShiftedUint8WeightPerChannelFloat', 'ShiftedUint8ActPerTensorFloat']
 
 SCALING_MIN_VAL = 1e-10  # B/quant/base.py:115-123, 169-182
 
@@ -61,9 +63,13 @@ def Int8WeightPerTensorFloat(weights, bit_width: int = 8) -> RescalingIntQuant:
 
 
 def _act_quant(signed: bool, bit_width: int, scaling_impl_type: str, collect_stats_steps: int,
-               channels: Optional[int], scaling_init: Optional[float]) -> RescalingIntQuant:
+               channels: Optional[int], scaling_init: Optional[float], scaling_stats_op: str = 'max'
+               ) -> RescalingIntQuant:
     if channels is None:
-        view, stats, shape = OverTensorView(), AbsMax(), ()
+        # the reference's default statistic is the 99.999th percentile (B/quant/base.py:68-75);
+        # scaling_stats_op='max' is its supported StatsOp.MAX override
+        stats = AbsPercentile(99.999, None) if scaling_stats_op == 'percentile' else AbsMax()
+        view, shape = OverTensorView(), ()
     else:
         # scaling_per_output_channel=True, per_channel_broadcastable_shape=(1,C,1,1),
         # scaling_stats_permute_dims=(1,0,2,3)  (B/quant/solver/act.py:91-105)
@@ -84,18 +90,22 @@ def _act_quant(signed: bool, bit_width: int, scaling_impl_type: str, collect_sta
 
 
 def Int8ActPerTensorFloat(scaling_impl_type: str = 'parameter_from_stats', collect_stats_steps: int = 300,
-                          bit_width: int = 8, scaling_init: Optional[float] = None) -> RescalingIntQuant:
-    """IntQuant + ParamFromRuntime...Scaling + PerTensorFloatScaling8bit + ActQuantSolver
-    (B/quant/scaled_int.py:170-180) with the supported override scaling_stats_op = MAX (the reference's
-    default statistic, the 99.999th percentile, is a selection kernel and not on this path yet: SURVEY 8f).
-    Collects AbsMax for `collect_stats_steps` training steps, then learns the scale."""
-    return _act_quant(True, bit_width, scaling_impl_type, collect_stats_steps, None, scaling_init)
+                          bit_width: int = 8, scaling_init: Optional[float] = None,
+                          scaling_stats_op: str = 'percentile') -> RescalingIntQuant:
+    """IntQuant + ParamFromRuntimePercentileScaling + PerTensorFloatScaling8bit + ActQuantSolver
+    (B/quant/scaled_int.py:170-180): collects the 99.999th percentile of |x| (scaling_stats_op='max':
+    AbsMax, the reference's StatsOp.MAX override) for `collect_stats_steps` training steps, then learns
+    the scale."""
+    return _act_quant(True, bit_width, scaling_impl_type, collect_stats_steps, None, scaling_init,
+                      scaling_stats_op)
 
 
 def Uint8ActPerTensorFloat(scaling_impl_type: str = 'parameter_from_stats', collect_stats_steps: int = 300,
-                           bit_width: int = 8, scaling_init: Optional[float] = None) -> RescalingIntQuant:
+                           bit_width: int = 8, scaling_init: Optional[float] = None,
+                           scaling_stats_op: str = 'percentile') -> RescalingIntQuant:
     """unsigned variant for post-ReLU activations (B/quant/scaled_int.py:183-193)"""
-    return _act_quant(False, bit_width, scaling_impl_type, collect_stats_steps, None, scaling_init)
+    return _act_quant(False, bit_width, scaling_impl_type, collect_stats_steps, None, scaling_init,
+                      scaling_stats_op)
 
 
 def Int8ActPerChannelFloat(channels: int, scaling_impl_type: str = 'stats', collect_stats_steps: int = 300,
@@ -103,3 +113,53 @@ def Int8ActPerChannelFloat(channels: int, scaling_impl_type: str = 'stats', coll
     """Int8ActPerTensorFloat with scaling_per_output_channel=True over NCHW channel `channels`
     (the layout of BASELINE.json's metric)"""
     return _act_quant(True, bit_width, scaling_impl_type, collect_stats_steps, channels, None)
+
+
+def _shifted_weight_quant(weights, per_channel: bool, bit_width: int) -> RescalingIntQuant:
+    """ShiftedMinUintQuant + MinMaxStatsScaling (B/quant/base.py:60-65,137-150): unsigned codes, scale from
+    max - min, integer zero-point from -min / scale; both statistics are back-propagated through"""
+    tracked = _params(weights)
+    w = tracked[0]
+    if per_channel:
+        shape = (w.shape[0],) + (1,) * (w.dim() - 1)
+        view = lambda: OverOutputChannelView(None)  # noqa: E731
+        scale_stat, zp_stat, cat = AbsMinMax(1), NegativeMinOrZero(1), 1
+    else:
+        shape = ()
+        view = lambda: OverTensorView()  # noqa: E731
+        scale_stat, zp_stat, cat = AbsMinMax(), NegativeMinOrZero(), 0
+    int_quant = IntQuant(narrow_range=False, signed=False, float_to_int_impl=RoundSte(),
+                         tensor_clamp_impl=TensorClampSte())
+    return RescalingIntQuant(
+        int_quant,
+        StatsFromParameterScaling(scale_stat, view(), cat, tracked, FloatRestrictValue(), shape,
+                                  affine_rescaling=False, scaling_min_val=SCALING_MIN_VAL),
+        IntScaling(signed=False, narrow_range=False),
+        StatsFromParameterZeroPoint(int_quant, True, view(), cat, zp_stat, shape, tracked),
+        BitWidthConst(bit_width))
+
+
+def ShiftedUint8WeightPerTensorFloat(weights, bit_width: int = 8) -> RescalingIntQuant:
+    """B/quant/shifted_scaled_int.py:37-52"""
+    return _shifted_weight_quant(weights, False, bit_width)
+
+
+def ShiftedUint8WeightPerChannelFloat(weights, bit_width: int = 8) -> RescalingIntQuant:
+    """B/quant/shifted_scaled_int.py:55-70"""
+    return _shifted_weight_quant(weights, True, bit_width)
+
+
+def ShiftedUint8ActPerTensorFloat(collect_stats_steps: int = 300, bit_width: int = 8) -> RescalingIntQuant:
+    """ShiftedParamFromPercentileUintQuant + ParamFromRuntimePercentileIntervalScaling
+    (B/quant/shifted_scaled_int.py:19-34, base.py:87-95,153-166): scale from the 0.001..99.999 percentile
+    interval and zero-point from the 0.001th percentile, both collected for `collect_stats_steps`
+    training steps and then learned"""
+    int_quant = IntQuant(narrow_range=False, signed=False, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp())
+    return RescalingIntQuant(
+        int_quant,
+        ParameterFromRuntimeStatsScaling(collect_stats_steps, PercentileInterval(0.001, 99.999, None),
+                                         OverTensorView(), (), FloatRestrictValue(), 0.1, SCALING_MIN_VAL),
+        IntScaling(signed=False, narrow_range=False),
+        ParameterFromRuntimeZeroPoint(collect_stats_steps, int_quant, True, NegativePercentileOrZero(0.001, None),
+                                      (), OverTensorView(), 0.1),
+        BitWidthConst(bit_width))

@@ -531,10 +531,109 @@ def gen_percentile():
     st.save()
 
 
+# ------------------------------------------------------------------------------------------------
+# G. asymmetric ("shifted") quantizers: integer zero-point from statistics (B/quant/shifted_scaled_int.py)
+# ------------------------------------------------------------------------------------------------
+def gen_shifted():
+    from brevitas.core.stats import NegativeMinOrZero, NegativePercentileOrZero, PercentileInterval
+    from brevitas.core.zero_point import ParameterFromRuntimeZeroPoint, StatsFromParameterZeroPoint
+    st = Store('shifted')
+    for dn in ('f32', 'bf16'):
+        for tag, per_channel in (('per_tensor', False), ('per_channel', True)):
+            w = torch.randn(10, 6, 3, 3) * 0.1 + 0.03
+            w[4] = w[4].abs()  # a channel without negative values: zero-point offset 0
+            w = torch.nn.Parameter(w.to(DT[dn]))
+            if per_channel:
+                shape, mk, s_stat, z_stat, cat = (10, 1, 1, 1), (lambda: OverOutputChannelView(None)), AbsMinMax(1), \
+                    NegativeMinOrZero(1), 1
+            else:
+                shape, mk, s_stat, z_stat, cat = (), (lambda: OverTensorView()), AbsMinMax(), NegativeMinOrZero(), 0
+            iq = IntQuant(narrow_range=False, signed=False, float_to_int_impl=RoundSte(),
+                          tensor_clamp_impl=TensorClampSte())
+            q = RescalingIntQuant(
+                iq, StatsFromParameterScaling(s_stat, mk(), cat, [w], FloatRestrictValue(), shape, False, 1e-10),
+                IntScaling(signed=False, narrow_range=False),
+                StatsFromParameterZeroPoint(iq, True, mk(), cat, z_stat, shape, [w]), BitWidthConst(8))
+            y, scale, zp, bwt = q(w)
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'graph': 'shifted_weight', 'tag': tag, 'dtype': dn}, x=w.data, g=g, y=y, scale=scale, zp=zp,
+                    dx=w.grad)
+        iq = IntQuant(narrow_range=False, signed=False, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp())
+        q = RescalingIntQuant(
+            iq, ParameterFromRuntimeStatsScaling(2, PercentileInterval(0.001, 99.999, None), OverTensorView(), (),
+                                                 FloatRestrictValue(), 0.1, 1e-10),
+            IntScaling(signed=False, narrow_range=False),
+            ParameterFromRuntimeZeroPoint(2, iq, True, NegativePercentileOrZero(0.001, None), (), OverTensorView(), 0.1),
+            BitWidthConst(8))
+        q.train()
+        for step in range(4):
+            x = (torch.randn(4, 6, 9, 9) * (1.0 + 0.3 * step) + 0.5).to(DT[dn])
+            xi = x.clone().requires_grad_(True)
+            q.zero_grad()
+            y, scale, zp, bwt = q(xi)
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'graph': 'shifted_act', 'dtype': dn, 'step': step}, x=x, g=g, y=y, scale=scale, zp=zp, dx=xi.grad,
+                    zp_buffer=q.zero_point_impl.buffer.clone(), zp_value=q.zero_point_impl.value.detach().clone(),
+                    scale_value=q.scaling_impl.value.detach().clone())
+        sd = q.state_dict()
+        st.case({'graph': 'shifted_act_state_dict', 'dtype': dn, 'keys': sorted(sd.keys())})
+    st.save()
+
+
+# ------------------------------------------------------------------------------------------------
+# H. remaining quantizer variants of the same elementwise family (B/core/quant/{binary,ternary,int_base,int}.py)
+# ------------------------------------------------------------------------------------------------
+def gen_variants():
+    from brevitas.core.quant import (BinaryQuant, ClampedBinaryQuant, DecoupledIntQuant, TernaryQuant,
+                                     TruncIntQuant)
+    st = Store('variants')
+    for dn in ('f32', 'bf16'):
+        x = (torch.randn(5, 7, 3) * 0.8).to(DT[dn])
+        x.view(-1)[::11] = 0.0
+        for name, mk in (('binary', lambda: BinaryQuant(ParameterScaling(0.7))),
+                         ('clamped_binary', lambda: ClampedBinaryQuant(ParameterScaling(0.7))),
+                         ('ternary', lambda: TernaryQuant(ParameterScaling(0.9), 0.5))):
+            q = mk()
+            xi = x.clone().requires_grad_(True)
+            y, scale, zp, bwt = q(xi)
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'quant': name, 'dtype': dn}, x=x, g=g, y=y, scale=scale, zp=zp, bit_width=bwt, dx=xi.grad,
+                    dvalue=q.scaling_impl.value.grad)
+        # decoupled: rounding grid from pre_scale, de-quantization with scale
+        dq = DecoupledIntQuant(narrow_range=True, signed=True)
+        xi = x.clone().requires_grad_(True)
+        pre_scale, scale = torch.tensor(0.02), torch.tensor(0.013)
+        y = dq(pre_scale, torch.tensor(0.), scale, torch.tensor(0.), torch.tensor(4.), xi)
+        g = torch.randn(y.shape).to(y.dtype)
+        y.backward(g)
+        st.case({'quant': 'decoupled', 'dtype': dn}, x=x, g=g, y=y, dx=xi.grad, pre_scale=pre_scale, scale=scale)
+        # truncation of an 8-bit quantized value to 5 bits
+        for rm, impl in (('floor', FloorSte), ('round', RoundSte)):
+            tq = TruncIntQuant(impl(), BitWidthConst(5))
+            s8 = torch.tensor(0.05)
+            xq = (torch.randint(-128, 128, (6, 9)).float() * s8).to(DT[dn])
+            xi = xq.clone().requires_grad_(True)
+            y, so, zo, bo = tq(xi, s8, torch.tensor(0.), torch.tensor(8.))
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'quant': 'trunc', 'round': rm, 'dtype': dn}, x=xq, g=g, y=y, dx=xi.grad, scale=so, bit_width=bo)
+    # doctests: B/core/quant/int_base.py:118-126, ternary.py:32-44
+    inp = torch.Tensor([0.042, -0.053, 0.31, -0.44])
+    y = DecoupledIntQuant(narrow_range=True, signed=True)(torch.tensor(0.02), torch.tensor(0.), torch.tensor(0.01),
+                                                          torch.tensor(0.), torch.tensor(4.), inp)
+    st.case({'quant': 'decoupled_doctest'}, x=inp, y=y)
+    y, scale, zp, bwt = TernaryQuant(ConstScaling(1.0), 0.5)(torch.Tensor([0.04, -0.6, 3.3]))
+    st.case({'quant': 'ternary_doctest'}, x=torch.Tensor([0.04, -0.6, 3.3]), y=y, scale=scale, zp=zp, bit_width=bwt)
+    st.save()
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     only = sys.argv[1:]
-    if not only or not set(only) <= {'act_fused', 'percentile'}:
+    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants'}:
         # the first four files were generated in ONE run, in this order, from a single seed
         torch.manual_seed(123456)
         gen_ste()
@@ -547,3 +646,9 @@ if __name__ == '__main__':
     if not only or 'percentile' in only:
         torch.manual_seed(123458)
         gen_percentile()
+    if not only or 'shifted' in only:
+        torch.manual_seed(123459)
+        gen_shifted()
+    if not only or 'variants' in only:
+        torch.manual_seed(123460)
+        gen_variants()
