@@ -93,10 +93,24 @@ class KernelTimer:
         return sum(ts) / len(ts) if ts else None
 
 
+def usable_cpus():
+    """host threads this process may really use: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            quota, period = fh.read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(shape, dtype, per_channel, budget_s=12.0):
     """time the oracle (oracle/, a port of the reference algorithm) on a bounded sample"""
     import numpy as np
 
+    os.environ.setdefault('OMP_NUM_THREADS', str(usable_cpus()))  # before libgomp starts its pool
     import oracle as O
     O.build()
     n_full, c, h, w = shape

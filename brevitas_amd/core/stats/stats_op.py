@@ -207,3 +207,28 @@ class AbsMinMax(torch.nn.Module):
     def forward(self, x: Tensor):
         max_val, min_val = _MinMaxFn.apply(x, self.stats_reduce_dim)
         return torch.abs(max_val - min_val)
+
+
+class AbsMaxAve(torch.nn.Module):
+    """mean over channels of the per-channel abs-max (B/core/stats/stats_op.py:161-170): the streaming
+    abs-max reduction followed by a mean over C values"""
+
+    def __init__(self, stats_reduce_dim: int) -> None:
+        super().__init__()
+        self.stats_reduce_dim = stats_reduce_dim
+
+    def forward(self, x: Tensor):
+        return torch.mean(_AbsMaxFn.apply(x, self.stats_reduce_dim))
+
+
+class AbsMaxL2(torch.nn.Module):
+    """L2 norm of the per-channel abs-max over sqrt(C) (B/core/stats/stats_op.py:173-185)"""
+
+    def __init__(self, stats_reduce_dim: int) -> None:
+        super().__init__()
+        self.stats_reduce_dim = stats_reduce_dim
+
+    def forward(self, x: torch.Tensor):
+        per_channel_max = _AbsMaxFn.apply(x, self.stats_reduce_dim)
+        out = torch.norm(per_channel_max, p=2)
+        return out / math.sqrt(per_channel_max.view(-1).shape[0])

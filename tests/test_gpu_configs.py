@@ -51,7 +51,8 @@ def test_config4_resnet50_layer3_block(oracle):
     x = torch.randn(n, 1024, 14, 14).to(torch.bfloat16)
     specs = [(1024, 256, 1, 0), (256, 256, 3, 1), (256, 1024, 1, 0)]
     layers = [QuantConv2d(ci, co, k, padding=p, bias=False, weight_quant=Q.Int8WeightPerChannelFloat,
-                          input_quant=Q.Int8ActPerTensorFloat(collect_stats_steps=300), dtype=torch.bfloat16,
+                          input_quant=Q.Int8ActPerTensorFloat(collect_stats_steps=300, scaling_stats_op='max'),
+                          dtype=torch.bfloat16,
                           device=DEV) for ci, co, k, p in specs]
     h = x.to(DEV)
     for layer in layers:
@@ -86,7 +87,7 @@ def test_config5_linear_int4_weight_int8_act(oracle):
     from brevitas_amd.nn import QuantLinear
     torch.manual_seed(123456)
     layer = QuantLinear(8192, 8192, bias=False, weight_quant=Q.Int4WeightPerChannelFloat,
-                        input_quant=Q.Int8ActPerTensorFloat(), dtype=torch.bfloat16, device=DEV)
+                        input_quant=Q.Int8ActPerTensorFloat(scaling_stats_op='max'), dtype=torch.bfloat16, device=DEV)
     with torch.no_grad():
         layer.weight.copy_((torch.randn(8192, 8192) * 0.01).to(torch.bfloat16))
     x = torch.randn(64, 8192).to(torch.bfloat16)

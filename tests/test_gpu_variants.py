@@ -31,7 +31,13 @@ def test_sign_quantizers(c):
     assert_bits(scale, c, 'scale')
     assert float(zp) == float(c.f32('zp')) and float(bw) == float(c.f32('bit_width'))
     y.backward(c.torch('g', DEV))
-    assert_bits(x.grad, c, 'dx')
+    if c['dtype'] == 'f32':
+        assert_bits(x.grad, c, 'dx')
+    else:
+        # dx = g * scale with a 0-dim float32 scale next to a bf16 tensor: torch's device kernels round
+        # the scalar to bf16 first, the CPU kernels (golden) do not -- one bf16 ulp apart at most
+        got, ref = x.grad.float().cpu(), c.torch('dx').float()
+        assert bool(((got - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-30).all())
     want = c.f32('dvalue').reshape(-1)
     got = q.scaling_impl.value.grad.float().cpu().numpy().reshape(-1)
     np.testing.assert_allclose(got, want, rtol=2e-2 if c['dtype'] == 'bf16' else 1e-5, atol=1e-6)

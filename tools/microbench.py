@@ -34,6 +34,8 @@ def main():
         y = torch.empty_like(x)
         t = timeit(lambda: y.copy_(x))
         print('%s copy           %.3f ms  %.2f TB/s' % (name, t, 2 * b * n / t / 1e9))
+        t = timeit(lambda: nat.unary(nat.OP_ABS, x))
+        print('%s |x| map kernel  %.3f ms  %.2f TB/s (grid-stride, default cache policy)' % (name, t, 2 * b * n / t / 1e9))
         for tag, ch in (('per-tensor', 1), ('per-channel', C)):
             outer, inner = (N, H * W) if ch > 1 else (1, n)
             t = timeit(lambda: nat.stats(nat.STAT_ABSMAX, x, outer, ch, inner))
