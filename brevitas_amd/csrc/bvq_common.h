@@ -223,7 +223,7 @@ int default_piece_chunks();
 int pick_vec(int max_vec, int64_t rows, int64_t row_len, const void* const* ptrs, const int* elsizes,
              int nptr);
 
-Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec);
+Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, int64_t unit_cap = 0);
 
 static inline unsigned grid_for_units(int64_t units) {
   return (unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock);

@@ -65,12 +65,12 @@ int max_units_per_channel() {
   static int v = [] {
     const char* e = getenv("BVQ_MAX_UNITS_PER_CHANNEL");
     int n = e ? atoi(e) : 0;
-    return (n >= 1 && n <= (1 << 24)) ? n : 4096;
+    return (n >= 1 && n <= (1 << 24)) ? n : (1 << 17);
   }();
   return v;
 }
 
-Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec) {
+Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, int64_t unit_cap) {
   Tiling t;
   t.outer = outer;
   t.channels = channels;
@@ -80,9 +80,10 @@ Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec) {
   t.rpu = 1;
   t.reverse = 0;
   if (row_len >= piece) {
-    // long rows: cut them.  Keep the number of units per channel bounded: per-unit partials are
-    // combined by one workgroup per channel, and a per-tensor quantizer is one very long row.
-    int64_t max_ppr = max_units_per_channel() / (outer > 0 ? outer : 1);
+    // long rows: cut them into default-sized pieces (a per-tensor quantizer is one very long row: ~10^5
+    // units, whose partials the finish kernels combine in two stages), bounded by unit_cap per channel.
+    if (unit_cap <= 0) unit_cap = max_units_per_channel();
+    int64_t max_ppr = unit_cap / (outer > 0 ? outer : 1);
     if (max_ppr < 1) max_ppr = 1;
     if (row_len > piece * max_ppr) {
       piece = (row_len + max_ppr - 1) / max_ppr;

@@ -20,6 +20,7 @@ namespace bvq {
 constexpr int kDigitBits = 11;
 constexpr int kBins = 1 << kDigitBits;
 constexpr int kSelUnroll = 4;
+constexpr int64_t kSelUnitCap = 4096;  // units per channel
 
 // order-preserving key of a value
 template <typename T, bool ABS>
@@ -246,7 +247,8 @@ extern "C" int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t oute
   int vec = pick_vec(full, t_outer * channels, row_len, ptrs, els, 1);
   vec = vec == full ? full : 1;
   SelArgs a;
-  a.t = make_tiling(t_outer, (int32_t)channels, row_len, vec);
+  // every wave flushes a 2048-bin histogram: keep the waves few and their pieces long
+  a.t = make_tiling(t_outer, (int32_t)channels, row_len, vec, kSelUnitCap);
   a.x = x;
   a.prefix = prefix;
   const bool nt = outer * channels * inner * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();

@@ -137,24 +137,45 @@ struct ScaleEpilogue {
   float int_threshold;
 };
 
-// one workgroup per channel; combines the per-unit partials of that channel
+// Combines the per-unit partials of one channel.  grid = (channels, splits): with splits == 1 the
+// workgroup of channel c reduces all of them and writes the statistic (and the scale epilogue); a
+// per-tensor statistic of a large activation has ~10^5 partials in its single channel, so there the
+// range is cut into `splits` slices whose results go to mid_a/mid_b[c * splits + s] and a second launch
+// of this kernel (nob = 1, ppr = splits) finishes.  max/min are exact, so the split changes nothing.
+constexpr int64_t kFinishSlice = 4096;  // partials per workgroup of the first stage
+
+static inline int32_t finish_splits(int64_t partials_per_channel) {
+  const int64_t s = (partials_per_channel + kFinishSlice - 1) / kFinishSlice;
+  return (int32_t)(s < 1 ? 1 : s);
+}
+
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void stat_finish_kernel(const uint32_t* __restrict__ part_a,
                                                              const uint32_t* __restrict__ part_b,
                                                              void* out, int out_dtype, int in_dtype,
                                                              int64_t nob, int32_t channels,
-                                                             int64_t ppr, ScaleEpilogue ep) {
+                                                             int64_t ppr, ScaleEpilogue ep,
+                                                             uint32_t* __restrict__ mid_a,
+                                                             uint32_t* __restrict__ mid_b) {
   __shared__ uint32_t sha[kBlock];
   __shared__ float shx[kBlock], shn[kBlock];
   __shared__ uint32_t shnan[kBlock];
   const int32_t c = blockIdx.x;
   const int64_t n = nob * ppr;  // units of this channel: (outer_block * channels + c) * ppr + piece
+  const int64_t slice = (n + gridDim.y - 1) / gridDim.y;
+  const int64_t k0 = (int64_t)blockIdx.y * slice;
+  const int64_t k1 = k0 + slice < n ? k0 + slice : n;
   uint32_t m = 0;
   float mx = -__builtin_inff(), mn = __builtin_inff();
   uint32_t nan = 0;
-  for (int64_t k = threadIdx.x; k < n; k += kBlock) {
-    const int64_t o = k / ppr, p = k - o * ppr;
-    const int64_t unit = (o * channels + c) * ppr + p;
+  for (int64_t k = k0 + threadIdx.x; k < k1; k += kBlock) {
+    int64_t unit;
+    if (nob == 1) {
+      unit = (int64_t)c * ppr + k;
+    } else {
+      const int64_t o = k / ppr, p = k - o * ppr;
+      unit = (o * channels + c) * ppr + p;
+    }
     if (KIND == BVQ_STAT_ABSMAX) {
       const uint32_t b = part_a[unit];
       m = b > m ? b : m;
@@ -181,7 +202,15 @@ __global__ __launch_bounds__(kBlock) void stat_finish_kernel(const uint32_t* __r
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && mid_a) {  // first stage of a split reduction
+    const int64_t slot = (int64_t)c * gridDim.y + blockIdx.y;
+    if (KIND == BVQ_STAT_ABSMAX) {
+      mid_a[slot] = sha[0];
+    } else {
+      mid_a[slot] = shnan[0] ? 0x7fc00000u : __builtin_bit_cast(uint32_t, shx[0]);
+      mid_b[slot] = __builtin_bit_cast(uint32_t, shn[0]);
+    }
+  } else if (threadIdx.x == 0) {
     if (KIND == BVQ_STAT_ABSMAX) {
       float v;
       if (in_dtype == BVQ_F16) {
@@ -529,7 +558,8 @@ extern "C" int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer,
   if (bad_dtype(dtype) || outer < 0 || channels < 1 || inner < 0) return -1;
   (void)kind;
   const int64_t units = worst_units(dtype, outer, channels, inner);
-  const int64_t partials = 2 * units * (int64_t)sizeof(uint32_t);
+  const int64_t mid = channels * (int64_t)finish_splits(units / channels + 1);
+  const int64_t partials = 2 * (units + mid) * (int64_t)sizeof(uint32_t);
   const int64_t tie = (channels > 1 ? channels : 2 + kTieCap) * (int64_t)sizeof(int64_t);
   return partials + tie + 256;
 }
@@ -562,7 +592,9 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
   int vec;
   StatArgs a;
   a.t = stat_tiling(dtype, x, nullptr, outer, channels, inner, vec);
-  const int64_t need = 2 * a.t.units * (int64_t)sizeof(uint32_t);
+  const int32_t splits = finish_splits(a.t.nob * a.t.ppr);
+  const int64_t mid_words = splits > 1 ? channels * (int64_t)splits : 0;
+  const int64_t need = 2 * (a.t.units + mid_words) * (int64_t)sizeof(uint32_t);
   if (workspace_bytes < need) {
     set_error("bvq_stats: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     return BVQ_ERR_WORKSPACE;
@@ -580,12 +612,28 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
     launch_stat<f16_t>(kind, pre_op, a, vec, nt, st);
   int rc = check_launch("bvq_stats");
   if (rc) return rc;
+  uint32_t* mid_a = splits > 1 ? a.part_b + a.t.units : nullptr;
+  uint32_t* mid_b = splits > 1 ? mid_a + mid_words : nullptr;
+  const ScaleEpilogue none = {};
+#define BVQ_FINISH(KIND)                                                                             \
+  do {                                                                                               \
+    if (splits > 1) {                                                                                \
+      stat_finish_kernel<KIND><<<dim3((unsigned)channels, (unsigned)splits), dim3(kBlock), 0, st>>>( \
+          a.part_a, a.part_b, out, out_dtype, dtype, a.t.nob, (int32_t)channels, a.t.ppr, none, mid_a, \
+          mid_b);                                                                                    \
+      stat_finish_kernel<KIND><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(                   \
+          mid_a, mid_b, out, out_dtype, dtype, 1, (int32_t)channels, splits, ep, nullptr, nullptr);  \
+    } else {                                                                                         \
+      stat_finish_kernel<KIND><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(                   \
+          a.part_a, a.part_b, out, out_dtype, dtype, a.t.nob, (int32_t)channels, a.t.ppr, ep, nullptr, \
+          nullptr);                                                                                  \
+    }                                                                                                \
+  } while (0)
   if (kind == BVQ_STAT_ABSMAX)
-    stat_finish_kernel<BVQ_STAT_ABSMAX><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(
-        a.part_a, a.part_b, out, out_dtype, dtype, a.t.nob, (int32_t)channels, a.t.ppr, ep);
+    BVQ_FINISH(BVQ_STAT_ABSMAX);
   else
-    stat_finish_kernel<BVQ_STAT_MINMAX><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(
-        a.part_a, a.part_b, out, out_dtype, dtype, a.t.nob, (int32_t)channels, a.t.ppr, ep);
+    BVQ_FINISH(BVQ_STAT_MINMAX);
+#undef BVQ_FINISH
   return check_launch("bvq_stats/finish");
 }
 

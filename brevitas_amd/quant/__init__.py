@@ -11,19 +11,21 @@ from typing import List, Optional, Sequence, Union
 import torch
 
 from brevitas_amd.core.bit_width import BitWidthConst
-from brevitas_amd.core.function_wrapper import (OverOutputChannelView, OverTensorView, RoundSte, TensorClamp,
+from brevitas_amd.core.function_wrapper import (CeilSte, OverOutputChannelView, OverTensorView, RoundSte, TensorClamp,
                                                 TensorClampSte)
 from brevitas_amd.core.quant import IntQuant, RescalingIntQuant
-from brevitas_amd.core.restrict_val import FloatRestrictValue
+from brevitas_amd.core.restrict_val import FloatRestrictValue, PowerOfTwoRestrictValue
 from brevitas_amd.core.scaling import (IntScaling, ParameterFromRuntimeStatsScaling, ParameterScaling,
-                                       RuntimeStatsScaling, StatsFromParameterScaling)
+                                       PowerOfTwoIntScaling, RuntimeStatsScaling, StatsFromParameterScaling)
 from brevitas_amd.core.stats import (AbsMax, AbsMinMax, AbsPercentile, NegativeMinOrZero, NegativePercentileOrZero,
                                      PercentileInterval)
 from brevitas_amd.core.zero_point import ParameterFromRuntimeZeroPoint, StatsFromParameterZeroPoint, ZeroZeroPoint
 
 __all__ = ['Int8WeightPerChannelFloat', 'Int4WeightPerChannelFloat', 'Int8WeightPerTensorFloat',
            'Int8ActPerTensorFloat', 'Uint8ActPerTensorFloat', 'Int8ActPerChannelFloat',
-           'ShiftedUint8WeightPerTensorFloat', 'ShiftedUint8WeightPerChannelFloat', 'ShiftedUint8ActPerTensorFloat']
+           'ShiftedUint8WeightPerTensorFloat', 'ShiftedUint8WeightPerChannelFloat', 'ShiftedUint8ActPerTensorFloat',
+           'Int8WeightPerTensorFixedPoint', 'Int8WeightPerChannelFixedPoint', 'Int8ActPerTensorFixedPoint',
+           'Uint8ActPerTensorFixedPoint', 'Uint8ActPerTensorFixedPointMaxInit']
 
 SCALING_MIN_VAL = 1e-10  # B/quant/base.py:115-123, 169-182
 
@@ -163,3 +165,60 @@ def ShiftedUint8ActPerTensorFloat(collect_stats_steps: int = 300, bit_width: int
         ParameterFromRuntimeZeroPoint(collect_stats_steps, int_quant, True, NegativePercentileOrZero(0.001, None),
                                       (), OverTensorView(), 0.1),
         BitWidthConst(bit_width))
+
+
+# ---- fixed point: power-of-two scales (B/quant/fixed_point.py:23-73, PerTensorPoTScaling8bit B/quant/base.py:185-191)
+
+def _pot():
+    return PowerOfTwoRestrictValue(CeilSte())
+
+
+def Int8WeightPerTensorFixedPoint(weights, bit_width: int = 8) -> RescalingIntQuant:
+    """NarrowIntQuant + MaxStatsScaling + PerTensorPoTScaling8bit (B/quant/fixed_point.py:23-34):
+    scale = 2^ceil(log2 max|w|) / 2^(b-1); the radix point follows the back-propagated statistic"""
+    tracked = _params(weights)
+    return RescalingIntQuant(
+        IntQuant(narrow_range=True, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClampSte()),
+        StatsFromParameterScaling(AbsMax(), OverTensorView(), 0, tracked, _pot(), (), affine_rescaling=False,
+                                  scaling_min_val=None),
+        PowerOfTwoIntScaling(signed=True), ZeroZeroPoint(), BitWidthConst(bit_width))
+
+
+def Int8WeightPerChannelFixedPoint(weights, bit_width: int = 8) -> RescalingIntQuant:
+    """Int8WeightPerTensorFixedPoint with scaling_per_output_channel=True: one radix point per output channel"""
+    tracked = _params(weights)
+    w = tracked[0]
+    shape = (w.shape[0],) + (1,) * (w.dim() - 1)
+    return RescalingIntQuant(
+        IntQuant(narrow_range=True, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClampSte()),
+        StatsFromParameterScaling(AbsMax(1), OverOutputChannelView(None), 1, tracked, _pot(), shape,
+                                  affine_rescaling=False, scaling_min_val=None),
+        PowerOfTwoIntScaling(signed=True), ZeroZeroPoint(), BitWidthConst(bit_width))
+
+
+def _act_fixed_point(signed: bool, collect_stats_steps: int, bit_width: int) -> RescalingIntQuant:
+    return RescalingIntQuant(
+        IntQuant(narrow_range=False, signed=signed, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+        ParameterFromRuntimeStatsScaling(collect_stats_steps, AbsPercentile(99.999, None), OverTensorView(), (),
+                                         _pot(), 0.1, SCALING_MIN_VAL),
+        PowerOfTwoIntScaling(signed=signed), ZeroZeroPoint(), BitWidthConst(bit_width))
+
+
+def Int8ActPerTensorFixedPoint(collect_stats_steps: int = 300, bit_width: int = 8) -> RescalingIntQuant:
+    """IntQuant + ParamFromRuntimePercentileScaling + PerTensorPoTScaling8bit (B/quant/fixed_point.py:37-47):
+    log2 of the 99.999th percentile is collected, then learned; the scale is 2^ceil(value) / 2^(b-1)"""
+    return _act_fixed_point(True, collect_stats_steps, bit_width)
+
+
+def Uint8ActPerTensorFixedPoint(collect_stats_steps: int = 300, bit_width: int = 8) -> RescalingIntQuant:
+    """unsigned variant (B/quant/fixed_point.py:50-60)"""
+    return _act_fixed_point(False, collect_stats_steps, bit_width)
+
+
+def Uint8ActPerTensorFixedPointMaxInit(max_val: float, bit_width: int = 8) -> RescalingIntQuant:
+    """UintQuant + ParamMinMaxInitScaling + PerTensorPoTScaling8bit (B/quant/fixed_point.py:63-76): learned
+    radix point initialised from a user-defined max_val"""
+    return RescalingIntQuant(
+        IntQuant(narrow_range=False, signed=False, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+        ParameterScaling(max_val, None, _pot(), None),
+        PowerOfTwoIntScaling(signed=False), ZeroZeroPoint(), BitWidthConst(bit_width))

@@ -630,10 +630,77 @@ def gen_variants():
     st.save()
 
 
+# ------------------------------------------------------------------------------------------------
+# I. restricted scales: power-of-two (fixed point, B/quant/fixed_point.py:23-73) and log-domain learned scales
+# ------------------------------------------------------------------------------------------------
+def gen_fixed_point():
+    from brevitas.core.restrict_val import LogFloatRestrictValue, PowerOfTwoRestrictValue
+    from brevitas.core.scaling import PowerOfTwoIntScaling
+    from brevitas.core.stats import AbsPercentile
+    st = Store('fixed_point')
+    for dn in ('f32', 'bf16'):
+        # Int8WeightPerTensorFixedPoint, and the same with one radix point per output channel
+        for tag, per_channel in (('per_tensor', False), ('per_channel', True)):
+            w = torch.nn.Parameter((torch.randn(12, 5, 3, 3) * 0.2).to(DT[dn]))
+            if per_channel:
+                scaling = StatsFromParameterScaling(AbsMax(1), OverOutputChannelView(None), 1, [w],
+                                                    PowerOfTwoRestrictValue(CeilSte()), (12, 1, 1, 1), False, None)
+            else:
+                scaling = StatsFromParameterScaling(AbsMax(), OverTensorView(), 0, [w],
+                                                    PowerOfTwoRestrictValue(CeilSte()), (), False, None)
+            q = RescalingIntQuant(
+                IntQuant(narrow_range=True, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClampSte()),
+                scaling, PowerOfTwoIntScaling(signed=True), ZeroZeroPoint(), BitWidthConst(8))
+            y, scale, zp, bwt = q(w)
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'graph': 'pot_weight', 'tag': tag, 'dtype': dn}, x=w.data, g=g, y=y, scale=scale, zp=zp, dx=w.grad)
+        # Int8ActPerTensorFixedPoint / Uint8ActPerTensorFixedPoint: percentile collected for 2 steps, then learned
+        for signed in (True, False):
+            q = RescalingIntQuant(
+                IntQuant(narrow_range=False, signed=signed, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+                ParameterFromRuntimeStatsScaling(2, AbsPercentile(99.999, None), OverTensorView(), (),
+                                                 PowerOfTwoRestrictValue(CeilSte()), 0.1, 1e-10),
+                PowerOfTwoIntScaling(signed=signed), ZeroZeroPoint(), BitWidthConst(8))
+            q.train()
+            for step in range(4):
+                x = (torch.randn(4, 6, 9, 9) * (1.0 + 0.4 * step)).to(DT[dn])
+                if not signed:
+                    x = torch.relu(x)
+                xi = x.clone().requires_grad_(True)
+                q.zero_grad()
+                y, scale, zp, bwt = q(xi)
+                g = torch.randn(y.shape).to(y.dtype)
+                y.backward(g)
+                vg = q.scaling_impl.value.grad
+                st.case({'graph': 'pot_act', 'signed': signed, 'dtype': dn, 'step': step}, x=x, g=g, y=y, scale=scale,
+                        dx=xi.grad, value=q.scaling_impl.value.detach().clone(),
+                        dvalue=None if vg is None else vg.clone())
+            q.eval()
+            x = (torch.randn(3, 6, 5, 5) * 2).to(DT[dn])
+            y, scale, zp, bwt = q(x)
+            st.case({'graph': 'pot_act_eval', 'signed': signed, 'dtype': dn}, x=x, y=y, scale=scale)
+        # Uint8ActPerTensorFixedPointMaxInit: learned log2-domain value initialised from max_val
+        for name, restrict, int_scaling in (
+                ('pot_param', lambda: PowerOfTwoRestrictValue(CeilSte()), lambda: PowerOfTwoIntScaling(signed=False)),
+                ('log_param', lambda: LogFloatRestrictValue(), lambda: IntScaling(signed=False, narrow_range=False))):
+            q = RescalingIntQuant(
+                IntQuant(narrow_range=False, signed=False, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+                ParameterScaling(0.75, None, restrict(), None), int_scaling(), ZeroZeroPoint(), BitWidthConst(8))
+            x = torch.relu(torch.randn(4, 5, 6) * 0.4).to(DT[dn])
+            xi = x.clone().requires_grad_(True)
+            y, scale, zp, bwt = q(xi)
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'graph': name, 'dtype': dn}, x=x, g=g, y=y, scale=scale, dx=xi.grad,
+                    value=q.scaling_impl.value.detach().clone(), dvalue=q.scaling_impl.value.grad)
+    st.save()
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     only = sys.argv[1:]
-    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants'}:
+    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point'}:
         # the first four files were generated in ONE run, in this order, from a single seed
         torch.manual_seed(123456)
         gen_ste()
@@ -652,3 +719,6 @@ if __name__ == '__main__':
     if not only or 'variants' in only:
         torch.manual_seed(123460)
         gen_variants()
+    if not only or 'fixed_point' in only:
+        torch.manual_seed(123461)
+        gen_fixed_point()

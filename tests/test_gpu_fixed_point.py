@@ -1,0 +1,130 @@
+"""Restricted scales: power-of-two / fixed-point quantizers and log-domain learned
+scales.  brevitas_amd.quant.*FixedPoint* against the reference's resolved graphs
+(tests/golden/fixed_point.npz).  Power-of-two scales are bit-exact (2^integer is exact on both
+sides), so y is too; dx is bit-exact away from the elements that receive the statistic's gradient.
+The log-domain learned scale goes through 2^float on the device's own libm, so there the scale is
+held to 2 ulp of the golden one and y to the oracle fed with the scale the device produced."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+from test_gpu_modules import assert_bits, to_np
+from test_gpu_shifted import _dx_check
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+CASES = G.load('fixed_point')
+
+
+@pytest.fixture(autouse=True)
+def cpu_scalar_semantics(monkeypatch):
+    import brevitas_amd.config as config
+    monkeypatch.setattr(config, 'SCALAR_OPERAND_MODE', 'cpu')
+
+
+def _assert_ulps(t, c, name, ulps):
+    """log2 runs on the device's own libm: the log-domain value may sit an ulp off the CPU's"""
+    got = t.detach().float().cpu().numpy().reshape(-1).view(np.int32).astype(np.int64)
+    want = c.f32(name).reshape(-1).view(np.int32).astype(np.int64)
+    if c['dtypes'][name] != 'f32':
+        got, want = got >> 16, want >> 16
+    assert np.all(np.abs(got - want) <= ulps), (name, got, want)
+
+
+def _is_pot(t):
+    m, _ = np.frexp(t.detach().float().cpu().numpy())
+    return np.all(m == 0.5)
+
+
+@pytest.mark.parametrize('c', [k for k in CASES if k['graph'] == 'pot_weight'],
+                         ids=lambda c: '%s-%s' % (c['tag'], c['dtype']))
+def test_pot_weight(c):
+    import brevitas_amd.quant as Q
+    w = torch.nn.Parameter(c.torch('x', DEV))
+    build = Q.Int8WeightPerChannelFixedPoint if c['tag'] == 'per_channel' else Q.Int8WeightPerTensorFixedPoint
+    q = build(w).to(DEV)
+    y, scale, zp, bw = q(w)
+    assert _is_pot(scale)
+    assert_bits(scale, c, 'scale')
+    assert_bits(y, c, 'y')
+    y.backward(c.torch('g', DEV))
+    channels = w.shape[0] if c['tag'] == 'per_channel' else 1
+    _dx_check(w.grad, c, channels)  # the arg-max of every channel also receives d(scale)
+
+
+@pytest.mark.parametrize('dn', ['f32', 'bf16'])
+@pytest.mark.parametrize('signed', [True, False])
+def test_pot_act(dn, signed):
+    import brevitas_amd.quant as Q
+    build = Q.Int8ActPerTensorFixedPoint if signed else Q.Uint8ActPerTensorFixedPoint
+    q = build(collect_stats_steps=2).to(DEV)
+    q.train()
+    for c in [k for k in CASES if k['graph'] == 'pot_act' and k['dtype'] == dn and k['signed'] == signed]:
+        x = c.torch('x', DEV).requires_grad_(True)
+        q.zero_grad()
+        y, scale, zp, bw = q(x)
+        # while statistics are collected the reference uses the clamped statistic itself, unrestricted
+        assert c['step'] < 2 or _is_pot(scale)
+        assert_bits(scale, c, 'scale')
+        assert_bits(y, c, 'y')
+        y.backward(c.torch('g', DEV))
+        _dx_check(x.grad, c, 2)
+        if c['step'] >= 2:  # learned phase: the value is the log2-domain parameter
+            _assert_ulps(q.scaling_impl.value, c, 'value', 2)
+            got, want = q.scaling_impl.value.grad.float().cpu().numpy(), c.f32('dvalue')
+            assert np.allclose(got, want, rtol=2e-3, atol=1e-4 * max(1.0, abs(float(want)))), (got, want)
+    q.eval()
+    c = [k for k in CASES if k['graph'] == 'pot_act_eval' and k['dtype'] == dn and k['signed'] == signed][0]
+    y, scale, zp, bw = q(c.torch('x', DEV))
+    assert_bits(scale, c, 'scale')
+    assert_bits(y, c, 'y')
+
+
+@pytest.mark.parametrize('c', [k for k in CASES if k['graph'] == 'pot_param'], ids=lambda c: c['dtype'])
+def test_pot_max_init(c):
+    import brevitas_amd.quant as Q
+    q = Q.Uint8ActPerTensorFixedPointMaxInit(0.75).to(DEV)
+    assert_bits(q.scaling_impl.value, c, 'value')  # math.log2 on the host
+    x = c.torch('x', DEV).requires_grad_(True)
+    y, scale, zp, bw = q(x)
+    assert_bits(scale, c, 'scale')
+    assert_bits(y, c, 'y')
+    y.backward(c.torch('g', DEV))
+    assert_bits(x.grad, c, 'dx')
+    got, want = q.scaling_impl.value.grad.float().cpu().numpy(), c.f32('dvalue')
+    assert np.allclose(got, want, rtol=2e-3), (got, want)
+
+
+@pytest.mark.parametrize('c', [k for k in CASES if k['graph'] == 'log_param'], ids=lambda c: c['dtype'])
+def test_log_domain_learned_scale(c):
+    import oracle as O
+    from brevitas_amd.core.bit_width import BitWidthConst
+    from brevitas_amd.core.function_wrapper import RoundSte, TensorClamp
+    from brevitas_amd.core.quant import IntQuant, RescalingIntQuant
+    from brevitas_amd.core.restrict_val import LogFloatRestrictValue
+    from brevitas_amd.core.scaling import IntScaling, ParameterScaling
+    from brevitas_amd.core.zero_point import ZeroZeroPoint
+    q = RescalingIntQuant(
+        IntQuant(narrow_range=False, signed=False, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+        ParameterScaling(0.75, None, LogFloatRestrictValue(), None), IntScaling(signed=False, narrow_range=False),
+        ZeroZeroPoint(), BitWidthConst(8)).to(DEV)
+    assert_bits(q.scaling_impl.value, c, 'value')
+    x = c.torch('x', DEV).requires_grad_(True)
+    y, scale, zp, bw = q(x)
+    got_s, want_s = scale.detach().cpu().numpy().view(np.int32), c.arr('scale').view(np.int32)
+    assert abs(int(got_s) - int(want_s)) <= 2, (got_s, want_s)
+    y.backward(c.torch('g', DEV))
+    # y / dx against the oracle fed with the scale the device produced
+    xn, code = O.from_torch(c.torch('x').reshape(-1))
+    gn, _ = O.from_torch(c.torch('g').reshape(-1))
+    d = O.make_desc(1, 1, xn.size, code, code, O.F32, O.F32, qmin=0.0, qmax=255.0, clamp_ste=False)
+    s_np = scale.detach().cpu().numpy().reshape(1).astype(np.float32)
+    y_o, _ = O.fakequant_fwd(d, xn, s_np, np.zeros(1, np.float32))
+    dx_o, ds_o, _ = O.fakequant_bwd(d, gn, xn, s_np, np.zeros(1, np.float32))
+    y_n, _ = O.from_torch(y.detach().cpu().reshape(-1))
+    dx_n, _ = O.from_torch(x.grad.cpu().reshape(-1))
+    assert np.array_equal(y_n, y_o)
+    assert np.array_equal(dx_n, dx_o)
+    got, want = q.scaling_impl.value.grad.float().cpu().numpy(), c.f32('dvalue')
+    assert np.allclose(got, want, rtol=5e-3), (got, want)

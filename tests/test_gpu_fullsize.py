@@ -99,6 +99,57 @@ def test_full_size_per_channel_properties(nat, act):
     assert torch.equal(bits(dx3), bits(dx)) and torch.equal(ds3, ds)
 
 
+def test_full_size_per_tensor_properties(nat, act):
+    """one scale for the whole [256,512,56,56] activation (Int8ActPerTensorFloat's layout): a single
+    channel of 4.1e8 elements, ~1e5 work units, partials combined by the two-stage finish kernels"""
+    x, g = act
+    n = x.numel()
+    flat, gf = x.reshape(-1), g.reshape(-1)
+    stat = nat.stats(nat.STAT_ABSMAX, flat, 1, 1, n)
+    assert torch.equal(stat.reshape(()), x.abs().amax())
+    st2, scale = nat.absmax_scale(flat, 1, 1, n, 1e-10, 128.0, torch.bfloat16)
+    assert torch.equal(st2, stat)
+    assert torch.equal(scale, (stat / torch.tensor(128.0, device=DEV)).clamp_min(1e-10))
+    mm = nat.stats(nat.STAT_MINMAX, flat, 1, 1, n)
+    assert torch.equal(mm.reshape(-1), torch.stack([x.amax(), x.amin()]))
+    zp = torch.zeros(1, device=DEV)
+    d = nat.QuantDesc(1, 1, n, nat.BF16, nat.BF16, nat.BF16, nat.F32, 0, 0, -128.0, 127.0, 0, 0, 0, 0)
+    y, codes = nat.fakequant_fwd(d, flat, scale, zp, want_codes=True)
+    t = torch.round(flat / scale + 0.0)
+    clipped = (t > 127.0) | (t < -128.0)
+    q = torch.clamp(t, -128.0, 127.0)
+    assert torch.equal(bits(y), bits(q * scale))
+    assert torch.equal(codes, q.to(torch.int32))
+    del codes, y
+    dx, ds, _, ties = nat.fakequant_bwd(d, gf, flat, scale, zp, True, False, tie_stat=stat)
+    assert torch.equal(bits(dx), bits(torch.where(clipped, torch.zeros_like(gf), (gf * scale) / scale)))
+    t1 = flat / scale
+    dt = torch.where(clipped, torch.zeros_like(gf), gf * scale)
+    a, b = (gf * q).double(), (dt * (t1 / scale)).double()
+    ref, mag = (a - b).sum(), (a.abs() + b.abs()).sum()
+    assert ds.numel() == 1
+    assert abs(float(ds.double()) - float(ref)) <= 1e-6 * float(mag) + 1e-6
+    del a, b, t1, dt, t, q
+    # full reduce: every position that attains the maximum is recorded (a handful at most here)
+    total = int(ties[0])
+    want_pos = torch.nonzero(flat.abs() == stat.reshape(())).reshape(-1)
+    assert total == want_pos.numel()
+    assert torch.equal(torch.sort(ties[2:2 + total]).values, want_pos)
+    # determinism of the split reduction
+    dx3, ds3, _ = nat.fakequant_bwd(d, gf, flat, scale, zp, True, False)
+    assert torch.equal(bits(dx3), bits(dx)) and torch.equal(ds3, ds)
+    # a zero-point gradient next to the scale gradient (both partial arrays through both stages)
+    dzp_d = nat.QuantDesc(1, 1, n, nat.BF16, nat.BF16, nat.BF16, nat.F32, 0, 0, 0.0, 255.0, 0, 0, 0, 0)
+    zp1 = torch.full((1,), 128.0, device=DEV)
+    dx4, ds4, dz4 = nat.fakequant_bwd(dzp_d, gf, flat, scale, zp1, True, True)
+    tz = torch.round(flat / scale + 128.0)
+    cz = (tz > 255.0) | (tz < 0.0)
+    dtz = torch.where(cz, torch.zeros_like(gf), gf * scale)
+    refz = dtz.double().sum() - (gf * scale).double().sum()
+    magz = dtz.double().abs().sum() + (gf * scale).double().abs().sum()
+    assert abs(float(dz4.double()) - float(refz)) <= 1e-6 * float(magz) + 1e-6
+
+
 def test_full_size_module_fused_equals_op_by_op(act):
     """config 3 through the module surface: the fused graph equals the reference's own op sequence
     run on the device (HIP-backed STE ops + torch's div/add/sub/mul)"""
