@@ -34,7 +34,8 @@ _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 EXPORTS = (
     'bvq_abi_version', 'bvq_last_error', 'bvq_unary', 'bvq_stats_pre', 'bvq_scalar_clamp', 'bvq_tensor_clamp',
     'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
-    'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
+    'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_passes',
+    'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
 
 
 class QuantDesc(ctypes.Structure):
@@ -78,6 +79,12 @@ def _load(path=None):
         'bvq_running_stats_update': (i32, [i32, vp, i32, vp, i64, dbl, i32, vp]),
         'bvq_kth_workspace_bytes': (i64, [i32, i64, i64, i64]),
         'bvq_kth_value': (i32, [i32, i32, vp, i64, i64, i64, i64, vp, vp, i64, vp]),
+        'bvq_kth_passes': (i32, [i32]),
+        'bvq_kth_hist_offset': (i64, [i32, i64, i32]),
+        'bvq_kth_begin': (i32, [i32, i64, i32, i64, dbl, vp, i64, vp]),
+        'bvq_kth_hist': (i32, [i32, i32, vp, i64, i64, i64, i32, vp, i64, vp]),
+        'bvq_kth_pick': (i32, [i32, i64, i32, i32, dbl, vp, i64, vp]),
+        'bvq_kth_finish': (i32, [i32, i32, i64, vp, vp, i64, vp]),
         'bvq_tie_info_bytes': (i64, [i64]),
         'bvq_stat_tie_scan': (i32, [i32, i32, vp, vp, i64, i64, i64, vp, vp, vp]),
         'bvq_stat_tie_apply': (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
@@ -335,6 +342,56 @@ def kth_value(x, k, outer, channels, inner, abs_key):
         if _timer is not None:
             _timer.after('bvq_kth_value')
     return out
+
+
+KTH_EXPLICIT, KTH_HIGH, KTH_LOW = 0, 1, 2
+_KBINS = 2048
+
+
+class KthSelectSteps:
+    """bvq_kth_value in steps (include/bvq.h) for a batch-sharded tensor: between hist(p) and pick(p)
+    the caller sums the returned counters over the shards (brevitas_amd.distributed.sharded_kth_value).
+    rule / q: the rank is derived on the device from the global element count (KTH_HIGH / KTH_LOW), or
+    KTH_EXPLICIT with k."""
+
+    def __init__(self, x, outer, channels, inner, abs_key, rule, q, k=0):
+        self.dev = require_device(x)
+        assert x.is_contiguous() and x.numel() == outer * channels * inner
+        self.x, self.layout, self.abs_key = x, (outer, channels, inner), int(abs_key)
+        self.rule, self.q, self.k = int(rule), float(q), int(k)
+        self.dt = dtype_code(x.dtype)
+        self.passes = int(lib.bvq_kth_passes(self.dt))
+        self.wsb = int(lib.bvq_kth_workspace_bytes(self.dt, outer, channels, inner))
+        if self.wsb < 0:
+            raise BvqError('bvq_kth_workspace_bytes: bad arguments')
+        self.ws = torch.empty(self.wsb, dtype=torch.uint8, device=self.dev)
+
+    def begin(self):
+        with _DeviceGuard(self.dev):
+            check(lib.bvq_kth_begin(self.dt, self.layout[1], self.rule, self.k, self.q, ptr(self.ws), self.wsb,
+                                    stream_ptr(self.dev)), 'bvq_kth_begin')
+
+    def hist(self, p):
+        """histogram this shard's elements for pass p -> the [channels * 2048] counters (int32 view of the
+        unsigned counters: a two's-complement sum over the shards is their unsigned sum)"""
+        outer, channels, inner = self.layout
+        with _DeviceGuard(self.dev):
+            check(lib.bvq_kth_hist(self.abs_key, self.dt, ptr(self.x), outer, channels, inner, p, ptr(self.ws),
+                                   self.wsb, stream_ptr(self.dev)), 'bvq_kth_hist')
+        off = int(lib.bvq_kth_hist_offset(self.dt, channels, p))
+        return self.ws[off:off + 4 * channels * _KBINS].view(torch.int32)
+
+    def pick(self, p):
+        with _DeviceGuard(self.dev):
+            check(lib.bvq_kth_pick(self.dt, self.layout[1], p, self.rule, self.q, ptr(self.ws), self.wsb,
+                                   stream_ptr(self.dev)), 'bvq_kth_pick')
+
+    def finish(self):
+        out = torch.empty(self.layout[1], dtype=self.x.dtype, device=self.dev)
+        with _DeviceGuard(self.dev):
+            check(lib.bvq_kth_finish(self.abs_key, self.dt, self.layout[1], ptr(out), ptr(self.ws), self.wsb,
+                                     stream_ptr(self.dev)), 'bvq_kth_finish')
+        return out
 
 
 def running_stats_update(running, stat, momentum, first_batch):

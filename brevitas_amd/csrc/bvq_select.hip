@@ -124,9 +124,23 @@ __global__ __launch_bounds__(kBlock) void kth_hist_kernel(SelArgs a) {
 
 // one workgroup per channel: find the bin that holds the k-th (1-indexed) matching key, append its
 // digit to the prefix and make k relative to that bin
+// rank rule of the percentile statistics (B/core/stats/stats_op.py:56,84,114-116), evaluated on the
+// device from the number of elements the first histogram counted -- for a tensor sharded over several
+// devices that is the GLOBAL count once the histograms have been summed, with no host round trip.
+// python evaluates `.01 * q * n` left to right in double; IEEE doubles give the same bits here.
+__device__ __forceinline__ int64_t rank_from_rule(int rule, double q, int64_t n) {
+  double v = 0.01 * q;
+  v = v * (double)n;
+  int64_t k = rule == BVQ_KTH_HIGH ? (int64_t)floor(v + 0.5) : (int64_t)ceil(v);
+  if (k < 1) k = 1;  // torch.kthvalue raises for k = 0; a device kernel cannot -- documented in bvq.h
+  if (k > n) k = n;
+  return k;
+}
+
 __global__ __launch_bounds__(kBlock) void kth_pick_kernel(const uint32_t* __restrict__ hist,
                                                           uint32_t* __restrict__ prefix,
-                                                          int64_t* __restrict__ krem, int32_t bits) {
+                                                          int64_t* __restrict__ krem, int32_t bits,
+                                                          int32_t rule, double q) {
   __shared__ int64_t part[kBlock];
   const int c = blockIdx.x;
   const uint32_t* h = hist + (int64_t)c * kBins;
@@ -138,15 +152,17 @@ __global__ __launch_bounds__(kBlock) void kth_pick_kernel(const uint32_t* __rest
   __syncthreads();
   // exclusive prefix over the 256 partial sums (serial on one thread: 256 adds)
   __shared__ int64_t before_me[kBlock];
+  __shared__ int64_t k_sh;
   if (threadIdx.x == 0) {
     int64_t run = 0;
     for (int t = 0; t < kBlock; ++t) {
       before_me[t] = run;
       run += part[t];
     }
+    k_sh = rule != BVQ_KTH_EXPLICIT ? rank_from_rule(rule, q, run) : krem[c];
   }
   __syncthreads();
-  const int64_t k = krem[c];
+  const int64_t k = k_sh;
   int64_t run = before_me[threadIdx.x];
   if (k > run && k <= run + mine) {  // exactly one thread owns the k-th element
     for (int j = 0; j < kPer; ++j) {
@@ -202,10 +218,180 @@ using namespace bvq;
 
 static int passes_for(int dtype) { return dtype == BVQ_F32 ? 3 : 2; }
 
-extern "C" int64_t bvq_kth_workspace_bytes(int dtype, int64_t outer, int64_t channels, int64_t inner) {
-  if (dtype < BVQ_F32 || dtype > BVQ_F16 || outer < 0 || channels < 1 || inner < 0) return -1;
+// workspace layout (depends on dtype and channels only):
+//   [passes][channels][kBins] uint32 histograms | [channels] int64 remaining rank | [channels] uint32 prefix
+struct SelWorkspace {
+  uint32_t* hist;
+  int64_t* krem;
+  uint32_t* prefix;
+  int64_t hist_words;
+};
+
+static int64_t sel_workspace_bytes(int dtype, int64_t channels) {
   return (int64_t)passes_for(dtype) * channels * kBins * (int64_t)sizeof(uint32_t) +
          channels * (int64_t)(sizeof(uint32_t) + sizeof(int64_t)) + 256;
+}
+
+static SelWorkspace sel_workspace(int dtype, int64_t channels, void* workspace) {
+  SelWorkspace w;
+  w.hist = reinterpret_cast<uint32_t*>(workspace);
+  w.hist_words = (int64_t)passes_for(dtype) * channels * kBins;
+  w.krem = reinterpret_cast<int64_t*>(w.hist + ((w.hist_words + 1) / 2) * 2);  // 8-byte aligned
+  w.prefix = reinterpret_cast<uint32_t*>(w.krem + channels);
+  return w;
+}
+
+static void pass_bits(int dtype, int pass, int& bits, int& shift) {
+  const int key_bits = dtype == BVQ_F32 ? 32 : 16;
+  int done = 0;
+  for (int p = 0;; ++p) {
+    bits = (key_bits - done) < kDigitBits ? (key_bits - done) : kDigitBits;
+    shift = key_bits - done - bits;
+    if (p == pass) return;
+    done += bits;
+  }
+}
+
+static int sel_check(const char* who, int dtype, int64_t channels, const void* workspace,
+                     int64_t workspace_bytes) {
+  if (dtype < BVQ_F32 || dtype > BVQ_F16 || channels < 1) {
+    set_error("%s: bad argument", who);
+    return BVQ_ERR_INVALID;
+  }
+  if (!workspace || workspace_bytes < sel_workspace_bytes(dtype, channels)) {
+    set_error("%s: workspace %lld < %lld bytes", who, (long long)workspace_bytes,
+              (long long)sel_workspace_bytes(dtype, channels));
+    return BVQ_ERR_WORKSPACE;
+  }
+  return BVQ_OK;
+}
+
+extern "C" int64_t bvq_kth_workspace_bytes(int dtype, int64_t outer, int64_t channels, int64_t inner) {
+  if (dtype < BVQ_F32 || dtype > BVQ_F16 || outer < 0 || channels < 1 || inner < 0) return -1;
+  return sel_workspace_bytes(dtype, channels);
+}
+
+extern "C" int bvq_kth_passes(int dtype) {
+  return (dtype < BVQ_F32 || dtype > BVQ_F16) ? -1 : passes_for(dtype);
+}
+
+extern "C" int64_t bvq_kth_hist_offset(int dtype, int64_t channels, int pass) {
+  if (dtype < BVQ_F32 || dtype > BVQ_F16 || channels < 1 || pass < 0 || pass >= passes_for(dtype)) return -1;
+  return (int64_t)pass * channels * kBins * (int64_t)sizeof(uint32_t);
+}
+
+extern "C" int bvq_kth_begin(int dtype, int64_t channels, int rule, int64_t k, double q, void* workspace,
+                             int64_t workspace_bytes, bvq_stream_t stream) {
+  int rc = sel_check("bvq_kth_begin", dtype, channels, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (rule < BVQ_KTH_EXPLICIT || rule > BVQ_KTH_LOW || (rule == BVQ_KTH_EXPLICIT && k < 1) ||
+      (rule != BVQ_KTH_EXPLICIT && !(q >= 0.0 && q <= 100.0))) {
+    set_error("bvq_kth_begin: bad rank (rule %d, k %lld, q %g)", rule, (long long)k, q);
+    return BVQ_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const SelWorkspace w = sel_workspace(dtype, channels, workspace);
+  (void)hipMemsetAsync(w.hist, 0, (size_t)w.hist_words * sizeof(uint32_t), st);
+  kth_init_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, st>>>(
+      w.prefix, w.krem, rule == BVQ_KTH_EXPLICIT ? k : 0, (int32_t)channels);
+  return check_launch("bvq_kth_begin");
+}
+
+extern "C" int bvq_kth_hist(int abs_key, int dtype, const void* x, int64_t outer, int64_t channels,
+                            int64_t inner, int pass, void* workspace, int64_t workspace_bytes,
+                            bvq_stream_t stream) {
+  int rc = sel_check("bvq_kth_hist", dtype, channels, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (outer < 0 || inner < 0 || pass < 0 || pass >= passes_for(dtype)) {
+    set_error("bvq_kth_hist: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  if (outer * inner == 0) return BVQ_OK;  // an empty shard adds nothing to the histogram
+  if (!x) {
+    set_error("bvq_kth_hist: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const SelWorkspace w = sel_workspace(dtype, channels, workspace);
+  const int64_t t_outer = channels > 1 ? outer : 1;
+  const int64_t row_len = channels > 1 ? inner : outer * inner;
+  const int full = 16 / dtype_size(dtype);
+  const void* ptrs[1] = {x};
+  const int els[1] = {dtype_size(dtype)};
+  int vec = pick_vec(full, t_outer * channels, row_len, ptrs, els, 1);
+  vec = vec == full ? full : 1;
+  SelArgs a;
+  // every wave flushes a 2048-bin histogram: keep the waves few and their pieces long
+  a.t = make_tiling(t_outer, (int32_t)channels, row_len, vec, kSelUnitCap);
+  a.x = x;
+  a.prefix = w.prefix;
+  a.hist = w.hist + (int64_t)pass * channels * kBins;
+  int bits, shift;
+  pass_bits(dtype, pass, bits, shift);
+  a.bits = bits;
+  a.shift = shift;
+  a.first_pass = pass == 0;
+  const bool nt = outer * channels * inner * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
+#define BVQ_HIST(T)                             \
+  do {                                          \
+    if (abs_key)                                \
+      launch_hist<T, true>(a, vec, nt, st);     \
+    else                                        \
+      launch_hist<T, false>(a, vec, nt, st);    \
+  } while (0)
+  if (dtype == BVQ_F32)
+    BVQ_HIST(float);
+  else if (dtype == BVQ_BF16)
+    BVQ_HIST(bf16_t);
+  else
+    BVQ_HIST(f16_t);
+#undef BVQ_HIST
+  return check_launch("bvq_kth_hist");
+}
+
+extern "C" int bvq_kth_pick(int dtype, int64_t channels, int pass, int rule, double q, void* workspace,
+                            int64_t workspace_bytes, bvq_stream_t stream) {
+  int rc = sel_check("bvq_kth_pick", dtype, channels, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (pass < 0 || pass >= passes_for(dtype) || rule < BVQ_KTH_EXPLICIT || rule > BVQ_KTH_LOW) {
+    set_error("bvq_kth_pick: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  const SelWorkspace w = sel_workspace(dtype, channels, workspace);
+  int bits, shift;
+  pass_bits(dtype, pass, bits, shift);
+  // the rank rule applies once, to the count of the first pass; later passes continue from krem
+  kth_pick_kernel<<<dim3((unsigned)channels), dim3(kBlock), 0, (hipStream_t)stream>>>(
+      w.hist + (int64_t)pass * channels * kBins, w.prefix, w.krem, bits, pass == 0 ? rule : BVQ_KTH_EXPLICIT, q);
+  return check_launch("bvq_kth_pick");
+}
+
+extern "C" int bvq_kth_finish(int abs_key, int dtype, int64_t channels, void* out, void* workspace,
+                              int64_t workspace_bytes, bvq_stream_t stream) {
+  int rc = sel_check("bvq_kth_finish", dtype, channels, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!out) {
+    set_error("bvq_kth_finish: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const SelWorkspace w = sel_workspace(dtype, channels, workspace);
+  const unsigned nb = (unsigned)((channels + 255) / 256);
+#define BVQ_STORE(T)                                                                       \
+  do {                                                                                     \
+    if (abs_key)                                                                           \
+      kth_store_kernel<T, true><<<dim3(nb), dim3(256), 0, st>>>(w.prefix, out, (int32_t)channels);  \
+    else                                                                                   \
+      kth_store_kernel<T, false><<<dim3(nb), dim3(256), 0, st>>>(w.prefix, out, (int32_t)channels); \
+  } while (0)
+  if (dtype == BVQ_F32)
+    BVQ_STORE(float);
+  else if (dtype == BVQ_BF16)
+    BVQ_STORE(bf16_t);
+  else
+    BVQ_STORE(f16_t);
+#undef BVQ_STORE
+  return check_launch("bvq_kth_finish");
 }
 
 extern "C" int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t outer, int64_t channels,
@@ -224,73 +410,11 @@ extern "C" int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t oute
     set_error("bvq_kth_value: null pointer");
     return BVQ_ERR_INVALID;
   }
-  const int64_t need = bvq_kth_workspace_bytes(dtype, outer, channels, inner);
-  if (workspace_bytes < need) {
-    set_error("bvq_kth_value: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
-    return BVQ_ERR_WORKSPACE;
+  int rc = bvq_kth_begin(dtype, channels, BVQ_KTH_EXPLICIT, k, 0.0, workspace, workspace_bytes, stream);
+  for (int p = 0; !rc && p < passes_for(dtype); ++p) {
+    rc = bvq_kth_hist(abs_key, dtype, x, outer, channels, inner, p, workspace, workspace_bytes, stream);
+    if (!rc) rc = bvq_kth_pick(dtype, channels, p, BVQ_KTH_EXPLICIT, 0.0, workspace, workspace_bytes, stream);
   }
-  hipStream_t st = (hipStream_t)stream;
-  const int passes = passes_for(dtype);
-  uint32_t* hist = reinterpret_cast<uint32_t*>(workspace);
-  const int64_t hist_words = (int64_t)passes * channels * kBins;
-  // keep the int64 array 8-byte aligned
-  int64_t* krem = reinterpret_cast<int64_t*>(hist + ((hist_words + 1) / 2) * 2);
-  uint32_t* prefix = reinterpret_cast<uint32_t*>(krem + channels);
-  (void)hipMemsetAsync(hist, 0, (size_t)hist_words * sizeof(uint32_t), st);
-  kth_init_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, st>>>(prefix, krem, k,
-                                                                                  (int32_t)channels);
-  const int64_t t_outer = channels > 1 ? outer : 1;
-  const int64_t row_len = channels > 1 ? inner : outer * inner;
-  const int full = 16 / dtype_size(dtype);
-  const void* ptrs[1] = {x};
-  const int els[1] = {dtype_size(dtype)};
-  int vec = pick_vec(full, t_outer * channels, row_len, ptrs, els, 1);
-  vec = vec == full ? full : 1;
-  SelArgs a;
-  // every wave flushes a 2048-bin histogram: keep the waves few and their pieces long
-  a.t = make_tiling(t_outer, (int32_t)channels, row_len, vec, kSelUnitCap);
-  a.x = x;
-  a.prefix = prefix;
-  const bool nt = outer * channels * inner * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
-  const int key_bits = dtype == BVQ_F32 ? 32 : 16;
-  int done_bits = 0;
-  for (int p = 0; p < passes; ++p) {
-    const int bits = (key_bits - done_bits) < kDigitBits ? (key_bits - done_bits) : kDigitBits;
-    a.hist = hist + (int64_t)p * channels * kBins;
-    a.bits = bits;
-    a.shift = key_bits - done_bits - bits;
-    a.first_pass = p == 0;
-#define BVQ_HIST(T)                             \
-  do {                                          \
-    if (abs_key)                                \
-      launch_hist<T, true>(a, vec, nt, st);     \
-    else                                        \
-      launch_hist<T, false>(a, vec, nt, st);    \
-  } while (0)
-    if (dtype == BVQ_F32)
-      BVQ_HIST(float);
-    else if (dtype == BVQ_BF16)
-      BVQ_HIST(bf16_t);
-    else
-      BVQ_HIST(f16_t);
-#undef BVQ_HIST
-    kth_pick_kernel<<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(a.hist, prefix, krem, bits);
-    done_bits += bits;
-  }
-  const unsigned nb = (unsigned)((channels + 255) / 256);
-#define BVQ_STORE(T)                                                                     \
-  do {                                                                                   \
-    if (abs_key)                                                                         \
-      kth_store_kernel<T, true><<<dim3(nb), dim3(256), 0, st>>>(prefix, out, (int32_t)channels); \
-    else                                                                                 \
-      kth_store_kernel<T, false><<<dim3(nb), dim3(256), 0, st>>>(prefix, out, (int32_t)channels); \
-  } while (0)
-  if (dtype == BVQ_F32)
-    BVQ_STORE(float);
-  else if (dtype == BVQ_BF16)
-    BVQ_STORE(bf16_t);
-  else
-    BVQ_STORE(f16_t);
-#undef BVQ_STORE
-  return check_launch("bvq_kth_value");
+  if (!rc) rc = bvq_kth_finish(abs_key, dtype, channels, out, workspace, workspace_bytes, stream);
+  return rc;
 }

@@ -10,6 +10,12 @@ over RCCL/xGMI (backend "nccl" on ROCm; "gloo" works for CPU tensors in tests). 
 latency-bound messages; they sit between the statistic kernel and the quantize kernel (resp. between
 the backward kernel and the tiny deposit kernel), so no extra pass over the tensor is made.
 
+Percentile statistics (the default Int8ActPerTensorFloat collects AbsPercentile for its first 300 steps)
+shard the same way, as a distributed radix select: every shard histograms one key digit of its own
+elements, the 8 KB-per-channel histogram is all-reduced (SUM), every shard picks the same digit; 2 rounds
+for 16-bit types, 3 for float32 (sharded_kth_value).  The rank k comes from the GLOBAL element count,
+which the first summed histogram already holds -- it is evaluated on the device, nothing goes to the host.
+
 Semantics: the result equals the single-device result on the concatenated batch (a max is exact and
 associative, so y is bit-identical); the reference itself has no cross-device reduction
 (nn.DataParallel replicas use local statistics).  The statistic's gradient is deposited
@@ -28,11 +34,19 @@ _NO_OWNER = float(1 << 30)
 
 
 def shard_over_batch(quantizer, group=None):
-    """Mark a RescalingIntQuant as operating on one batch shard of a tensor spread over `group`
-    (default: the world group).  Only the fused stats-scaled activation graph uses it."""
+    """Mark an activation quantizer (RescalingIntQuant) as operating on one batch shard of a tensor spread
+    over `group` (default: the world group): its fused stats-scaled graph and every statistic module
+    inside it (AbsMax, AbsMinMax, NegativeMinOrZero, the percentile family) then reduce over all shards.
+    Weight quantizers are replicated, not sharded: do not mark them."""
     if not dist.is_initialized():
         raise RuntimeError('shard_over_batch: torch.distributed is not initialised')
-    quantizer.bvq_shard_group = group if group is not None else dist.group.WORLD
+    group = group if group is not None else dist.group.WORLD
+    quantizer.bvq_shard_group = group
+    for m in quantizer.modules():
+        if getattr(m, 'bvq_shardable_stat', False):
+            m.bvq_shard_group = group
+        elif getattr(m, 'bvq_is_stat', False):
+            raise NotImplementedError('%s has no batch-sharded form' % type(m).__name__)
     return quantizer
 
 
@@ -47,19 +61,38 @@ def sync_stat_max(stat_f32: Tensor, group) -> Tensor:
     return stat_f32
 
 
-def sync_backward(ds_local: Tensor, tie_info: Tensor, channels: int, group
+def sync_stat_min(stat_f32: Tensor, group) -> Tensor:
+    if dist.get_world_size(group) > 1:
+        dist.all_reduce(stat_f32, op=dist.ReduceOp.MIN, group=group)
+    return stat_f32
+
+
+def sharded_kth_value(steps, group) -> Tensor:
+    """k-th value of the concatenation of all shards.  `steps`: brevitas_amd._native.KthSelectSteps over
+    this shard (or any object with its begin / hist(p) / pick(p) / finish and `passes`)."""
+    steps.begin()
+    for p in range(steps.passes):
+        h = steps.hist(p)
+        if dist.get_world_size(group) > 1:
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        steps.pick(p)
+    return steps.finish()
+
+
+def sync_backward(ds_local: Tensor, tie_info: Tensor, channels: int, group, first_only: bool = False
                   ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
     """Combine the shards' backward bookkeeping with ONE all-gather.
 
     ds_local : float32 [channels]   this shard's partial sums of the scale gradient
     tie_info : int64 buffer written by the backward kernel (include/bvq.h, bvq_stat_tie_scan):
                channels > 1: word c = first local position attaining the statistic, or -1
-               channels == 1: word 0 = number of local ties
+               channels == 1: word 0 = number of local ties -- or, with first_only (the statistic's
+               gradient goes to ONE element: kthvalue), the first local position like channels > 1
     returns (ds_total float32 [channels], tie_info with non-owned channels disabled,
              total_ties int64 [1] or None)
     """
     rank, world = world_of(group)
-    per_channel = channels > 1
+    per_channel = channels > 1 or first_only
     if per_channel:
         has = tie_info[:channels] >= 0
         key = torch.where(has, torch.full_like(ds_local, float(rank), dtype=torch.float64),

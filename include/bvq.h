@@ -208,6 +208,40 @@ int64_t bvq_kth_workspace_bytes(int dtype, int64_t outer, int64_t channels, int6
 int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
                   int64_t k, void* out, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
 
+/* The same selection in steps, for a tensor whose batch is sharded over several devices (one process
+ * per GPU): every shard histograms its own elements, the caller sums the histogram of the pass over the
+ * shards (one RCCL all-reduce of channels * 2048 uint32 counters, at byte offset bvq_kth_hist_offset()
+ * of the workspace) and every shard then picks the same digit -- the result is the k-th value of the
+ * CONCATENATED tensor, on every shard, with no other exchange:
+ *
+ *   bvq_kth_begin(...);
+ *   for (pass = 0; pass < bvq_kth_passes(dtype); ++pass) {
+ *     bvq_kth_hist(..., pass, ...);   all-reduce(SUM) workspace[offset(pass) .. + channels*2048*4);
+ *     bvq_kth_pick(..., pass, ...);
+ *   }
+ *   bvq_kth_finish(...);
+ *
+ * The rank is either explicit (BVQ_KTH_EXPLICIT, k >= 1) or derived ON THE DEVICE from the number of
+ * elements the first (summed) histogram counted, by the rule the percentile statistics use -- so the
+ * global element count never has to travel to the host:
+ *   BVQ_KTH_HIGH: k = floor(.01 * q * n + 0.5)   AbsPercentile, PercentileInterval's upper end
+ *   BVQ_KTH_LOW : k = ceil (.01 * q * n)         NegativePercentileOrZero, PercentileInterval's lower end
+ * (B/core/stats/stats_op.py:56,84,114-116), clamped to [1, n] (torch.kthvalue raises for k = 0; callers
+ * that need that error check q * n on the host).  Pass the same rule and q to bvq_kth_begin and to every
+ * bvq_kth_pick.  The workspace (bvq_kth_workspace_bytes) depends on dtype and channels only.  Counters
+ * are 32-bit: fewer than 2^32 elements per channel over all shards. */
+typedef enum bvq_kth_rule { BVQ_KTH_EXPLICIT = 0, BVQ_KTH_HIGH = 1, BVQ_KTH_LOW = 2 } bvq_kth_rule;
+int bvq_kth_passes(int dtype);
+int64_t bvq_kth_hist_offset(int dtype, int64_t channels, int pass);
+int bvq_kth_begin(int dtype, int64_t channels, int rule, int64_t k, double q, void* workspace,
+                  int64_t workspace_bytes, bvq_stream_t stream);
+int bvq_kth_hist(int abs_key, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+                 int pass, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
+int bvq_kth_pick(int dtype, int64_t channels, int pass, int rule, double q, void* workspace,
+                 int64_t workspace_bytes, bvq_stream_t stream);
+int bvq_kth_finish(int abs_key, int dtype, int64_t channels, void* out, void* workspace,
+                   int64_t workspace_bytes, bvq_stream_t stream);
+
 /* which elements attain the statistic */
 typedef enum bvq_match_kind {
   BVQ_MATCH_ABS = 0,   /* |x| == stat, deposit scaled by sgn(x): torch.max(torch.abs(x)) (AbsMax)   */

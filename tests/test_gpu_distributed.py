@@ -53,3 +53,76 @@ def test_sharded_path_equals_unsharded(nccl_world1, per_channel, dtype):
     if diff.numel():
         a, b = dx0.reshape(-1)[diff].float(), dx1.reshape(-1)[diff].float()
         assert bool(((a - b).abs() <= 2.0 ** -6 * (a.abs() + b.abs() + 1e-3)).all())
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16], ids=['bf16', 'f32', 'f16'])
+@pytest.mark.parametrize('channels', [1, 5])
+def test_stepwise_select_equals_kth_value(nccl_world1, dtype, channels):
+    """bvq_kth_begin/hist/pick/finish with the histogram routed through an RCCL all-reduce and the rank
+    derived on the device == bvq_kth_value with the host-computed rank == torch.kthvalue"""
+    import math
+
+    from brevitas_amd import _native as nat
+    from brevitas_amd.distributed import sharded_kth_value
+    torch.manual_seed(123456)
+    outer, inner = 7, 333
+    x = torch.randn(outer, channels, inner, device=DEV).to(dtype)
+    x[0, 0, :40] = 0.5
+    n = outer * inner
+    rows = x.permute(1, 0, 2).reshape(channels, -1).float()
+    for abs_key in (True, False):
+        src = rows.abs() if abs_key else rows
+        for rule, qs in ((nat.KTH_HIGH, (99.999, 50.0, 0.3)), (nat.KTH_LOW, (0.001, 25.0, 100.0))):
+            for q in qs:
+                k = int(math.floor(.01 * q * n + 0.5)) if rule == nat.KTH_HIGH else int(math.ceil(.01 * q * n))
+                steps = nat.KthSelectSteps(x.reshape(-1), outer, channels, inner, abs_key, rule, q)
+                got = sharded_kth_value(steps, nccl_world1)
+                want = nat.kth_value(x.reshape(-1), k, outer, channels, inner, abs_key)
+                assert torch.equal(got, want), (abs_key, rule, q)
+                assert torch.equal(got.float(), src.kthvalue(k, dim=1).values)
+    # explicit rank through the stepwise entry points
+    steps = nat.KthSelectSteps(x.reshape(-1), outer, channels, inner, True, nat.KTH_EXPLICIT, 0.0, k=17)
+    assert torch.equal(sharded_kth_value(steps, nccl_world1),
+                       nat.kth_value(x.reshape(-1), 17, outer, channels, inner, True))
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32], ids=['bf16', 'f32'])
+@pytest.mark.parametrize('name', ['Int8ActPerTensorFloat', 'ShiftedUint8ActPerTensorFloat',
+                                  'Int8ActPerTensorFloat-max', 'Int8ActPerTensorFixedPoint'])
+def test_sharded_named_act_quantizers_equal_unsharded(nccl_world1, name, dtype):
+    """percentile / min-max / abs-max statistics of the named activation quantizers through the sharded
+    statistic modules (collectives on RCCL) == the unsharded modules, over the collection steps, the switch
+    to the learned scale and one learned step"""
+    import brevitas_amd.quant as Q
+    from brevitas_amd.distributed import shard_over_batch
+
+    def build():
+        if name == 'Int8ActPerTensorFloat':
+            return Q.Int8ActPerTensorFloat(collect_stats_steps=2)
+        if name == 'Int8ActPerTensorFloat-max':
+            return Q.Int8ActPerTensorFloat(collect_stats_steps=2, scaling_stats_op='max')
+        if name == 'Int8ActPerTensorFixedPoint':
+            return Q.Int8ActPerTensorFixedPoint(collect_stats_steps=2)
+        return Q.ShiftedUint8ActPerTensorFloat(collect_stats_steps=2)
+
+    view = torch.int16 if dtype == torch.bfloat16 else torch.int32
+    qa, qb = build().to(DEV), shard_over_batch(build().to(DEV), nccl_world1)
+    qa.train(), qb.train()
+    torch.manual_seed(123456)
+    for step in range(4):
+        x = (torch.randn(4, 6, 9, 9, device=DEV) * (1.0 + 0.3 * step) + 0.2).to(dtype)
+        g = torch.randn_like(x)
+        outs = []
+        for q in (qa, qb):
+            xi = x.clone().requires_grad_(True)
+            q.zero_grad()
+            y, scale, zp, bw = q(xi)
+            y.backward(g)
+            outs.append((y.detach(), scale.detach().float(), zp.detach().float(), xi.grad))
+        (y0, s0, z0, dx0), (y1, s1, z1, dx1) = outs
+        assert torch.equal(y0.view(view), y1.view(view)) and torch.equal(s0, s1) and torch.equal(z0, z1), step
+        diff = (dx0.view(view) != dx1.view(view)).reshape(-1).nonzero().reshape(-1)
+        assert diff.numel() <= 4, (step, diff.numel())  # the elements holding a statistic: float32 route of gsum
+        if diff.numel():
+            a, b = dx0.reshape(-1)[diff].float(), dx1.reshape(-1)[diff].float()
+            assert bool(((a - b).abs() <= 2.0 ** -6 * (a.abs() + b.abs() + 1e-3)).all())
