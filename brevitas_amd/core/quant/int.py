@@ -156,11 +156,36 @@ class RescalingIntQuant(torch.nn.Module):
             return (not sc.training) or sc.counter >= sc.collect_stats_steps
         return False
 
+    def _collect_only(self, x: Tensor, pre_op: int, bit_width: Tensor):
+        """Calibration forward (brevitas_amd.graph.calibrate): advance the statistics of the scale and
+        zero-point modules exactly as a full forward would, hand the (activated) float tensor on, skip the
+        quantize/dequantize pass -- the reference computes it and a hook discards it
+        (B/graph/calibrate.py:115-127).  Not differentiable, like a PTQ forward under no_grad."""
+        if not isinstance(self.int_quant.delay_wrapper.delay_impl, _NoDelay):
+            raise NotImplementedError('calibration with quant_delay_steps')
+        with torch.no_grad():
+            fused = self._stats_plan(x, bit_width)
+            if fused is not None and fused[1]['runtime'] is not None:
+                sp, tmpl = fused
+                group = getattr(self, 'bvq_shard_group', None)
+                stat, scale = _fused.stats_scale(x.contiguous().reshape(-1), self.int_scaling_impl(bit_width), sp,
+                                                 group, pre_op)
+                tmpl['runtime'].update_running_stats(stat.view(sp.scaling_shape))
+                x_act = torch.relu(x) if pre_op == nat.PRE_RELU else x
+            else:
+                x_act = torch.relu(x) if pre_op == nat.PRE_RELU else x
+                threshold = self.scaling_impl(x_act)
+                scale = threshold / self.int_scaling_impl(bit_width)
+            zero_point = self.zero_point_impl(x_act, scale, bit_width)
+        return x_act, scale, zero_point, bit_width
+
     def bvq_forward_pre(self, x: Tensor, pre_op: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
         """forward(pre_op(x)) -- FusedActivationQuantProxy.forward (B/proxy/runtime_quant.py:80-84) -- with
         the activation folded into the statistic / quantizer kernels wherever those kernels apply, so
         the activation's own read + write (and its backward pass) disappear."""
         bit_width = self.msb_clamp_bit_width_impl()
+        if getattr(self, 'bvq_collect_only', False):
+            return self._collect_only(x, pre_op, bit_width)
         fused = self._stats_plan(x, bit_width)
         if fused is None and pre_op != nat.PRE_NONE:
             if type(self.int_quant) is IntQuant and type(self.zero_point_impl) is ZeroZeroPoint \

@@ -24,7 +24,7 @@ class _QuantWeightMixin:
 
     def quant_weight(self):
         """-> (dequantized weight, scale, zero_point, bit_width); identity if no weight quantizer"""
-        if self.weight_quant is None:
+        if self.weight_quant is None or getattr(self, 'bvq_disable_weight_quant', False):  # calibration
             return self.weight, None, None, None
         return self.weight_quant(self.weight)
 
