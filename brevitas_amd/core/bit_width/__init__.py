@@ -1,1 +1,2 @@
-from .const import BitWidthConst
+from .const import BitWidthConst, MsbClampBitWidth
+from .parameter import BitWidthParameter, RemoveBitwidthParameter

@@ -697,10 +697,60 @@ def gen_fixed_point():
     st.save()
 
 
+# ------------------------------------------------------------------------------------------------
+# J. learned bit width (B/core/bit_width/parameter.py): integer bounds and integer threshold become tensors
+# ------------------------------------------------------------------------------------------------
+def gen_learned_bw():
+    from brevitas.core.bit_width import BitWidthParameter, MsbClampBitWidth, RemoveBitwidthParameter
+    st = Store('learned_bw')
+    for dn in ('f32', 'bf16'):
+        # weight: per-channel abs-max scale, straight-through clamp -> d(bit width) through the scale only
+        w = torch.nn.Parameter((torch.randn(6, 4, 3, 3) * 0.3).to(DT[dn]))
+        q = RescalingIntQuant(
+            IntQuant(narrow_range=True, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClampSte()),
+            StatsFromParameterScaling(AbsMax(1), OverOutputChannelView(None), 1, [w], FloatRestrictValue(),
+                                      (6, 1, 1, 1), False, 1e-10),
+            IntScaling(signed=True, narrow_range=True), ZeroZeroPoint(), BitWidthParameter(4))
+        y, scale, zp, bwt = q(w)
+        g = torch.randn(y.shape).to(y.dtype)
+        y.backward(g)
+        st.case({'graph': 'weight', 'dtype': dn}, x=w.data, g=g, y=y, scale=scale, bit_width=bwt, dx=w.grad,
+                doffset=q.msb_clamp_bit_width_impl.bit_width_offset.grad)
+        # activation: learned scale, plain clamp -> d(bit width) through the scale AND the clamp bounds
+        for bits in (3, 6):
+            q = RescalingIntQuant(
+                IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+                ParameterScaling(1.5, None, FloatRestrictValue(), 1e-10),
+                IntScaling(signed=True, narrow_range=False), ZeroZeroPoint(), BitWidthParameter(bits))
+            x = (torch.randn(3, 5, 7) * 1.2).to(DT[dn])
+            xi = x.clone().requires_grad_(True)
+            y, scale, zp, bwt = q(xi)
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'graph': 'act', 'bits': bits, 'dtype': dn}, x=x, g=g, y=y, scale=scale, bit_width=bwt,
+                    dx=xi.grad, doffset=q.msb_clamp_bit_width_impl.bit_width_offset.grad,
+                    dvalue=q.scaling_impl.value.grad)
+    # the bit-width modules themselves
+    bw = BitWidthParameter(5, min_bit_width=3)
+    out = bw()
+    out.backward()
+    st.case({'graph': 'bit_width_parameter'}, out=out, offset=bw.bit_width_offset.data.clone(),
+            doffset=bw.bit_width_offset.grad)
+    for remove in (0, 3):
+        rm = RemoveBitwidthParameter(remove)
+        msb = MsbClampBitWidth(rm, 2, 16)
+        inp = torch.tensor(9.0, requires_grad=True)
+        out = msb(inp)
+        out.backward()
+        st.case({'graph': 'msb_clamp', 'remove': remove}, out=out, coeff=rm.bit_width_coeff.data.clone(),
+                dcoeff=rm.bit_width_coeff.grad, dinp=inp.grad)
+    st.save()
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     only = sys.argv[1:]
-    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point'}:
+    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point', 'learned_bw'}:
         # the first four files were generated in ONE run, in this order, from a single seed
         torch.manual_seed(123456)
         gen_ste()
@@ -722,3 +772,6 @@ if __name__ == '__main__':
     if not only or 'fixed_point' in only:
         torch.manual_seed(123461)
         gen_fixed_point()
+    if not only or 'learned_bw' in only:
+        torch.manual_seed(123462)
+        gen_learned_bw()
