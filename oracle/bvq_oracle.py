@@ -224,3 +224,7 @@ def step_stats_scaled(desc, x, g, min_val, int_threshold):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
