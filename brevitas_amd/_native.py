@@ -34,7 +34,8 @@ _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 EXPORTS = (
     'bvq_abi_version', 'bvq_last_error', 'bvq_unary', 'bvq_stats_pre', 'bvq_scalar_clamp', 'bvq_tensor_clamp',
     'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
-    'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_passes',
+    'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_abs_moments_workspace_bytes', 'bvq_abs_moments',
+    'bvq_abs_affine_bwd', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_passes',
     'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
 
 
@@ -77,6 +78,9 @@ def _load(path=None):
         'bvq_fakequant_bwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
         'bvq_absmax_scale': (i32, [i32, i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
         'bvq_running_stats_update': (i32, [i32, vp, i32, vp, i64, dbl, i32, vp]),
+        'bvq_abs_moments_workspace_bytes': (i64, [i32, i64, i64, i64]),
+        'bvq_abs_moments': (i32, [i32, vp, i64, i64, i64, vp, vp, i64, vp]),
+        'bvq_abs_affine_bwd': (i32, [i32, vp, vp, vp, vp, i64, i64, i64, vp]),
         'bvq_kth_workspace_bytes': (i64, [i32, i64, i64, i64]),
         'bvq_kth_value': (i32, [i32, i32, vp, i64, i64, i64, i64, vp, vp, i64, vp]),
         'bvq_kth_passes': (i32, [i32]),
@@ -346,6 +350,34 @@ def kth_value(x, k, outer, channels, inner, abs_key):
 
 KTH_EXPLICIT, KTH_HIGH, KTH_LOW = 0, 1, 2
 _KBINS = 2048
+
+
+def abs_moments(x, outer, channels, inner):
+    """-> float32 [2 * channels]: sum |x| then sum x^2 per channel of x[outer, channels, inner]"""
+    dev = require_device(x)
+    assert x.is_contiguous() and x.numel() == outer * channels * inner
+    dt = dtype_code(x.dtype)
+    sums = torch.empty(2 * channels, dtype=torch.float32, device=dev)
+    wsb = int(lib.bvq_abs_moments_workspace_bytes(dt, outer, channels, inner))
+    if wsb < 0:
+        raise BvqError('bvq_abs_moments_workspace_bytes: bad arguments')
+    ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
+    with _DeviceGuard(dev):
+        check(lib.bvq_abs_moments(dt, ptr(x), outer, channels, inner, ptr(sums), ptr(ws), wsb, stream_ptr(dev)),
+              'bvq_abs_moments')
+    return sums
+
+
+def abs_affine_bwd(x, a, b, outer, channels, inner):
+    """dx = sgn(x) * (a[c] + b[c] * |x|); a, b float32 [channels]"""
+    dev = require_device(x, a, b)
+    assert x.is_contiguous() and a.dtype == torch.float32 and b.dtype == torch.float32
+    assert a.numel() == channels and b.numel() == channels
+    dx = torch.empty_like(x)
+    with _DeviceGuard(dev):
+        check(lib.bvq_abs_affine_bwd(dtype_code(x.dtype), ptr(x), ptr(a.contiguous()), ptr(b.contiguous()), ptr(dx),
+                                     outer, channels, inner, stream_ptr(dev)), 'bvq_abs_affine_bwd')
+    return dx
 
 
 class KthSelectSteps:

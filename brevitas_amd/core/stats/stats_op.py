@@ -302,3 +302,111 @@ class AbsMaxL2(torch.nn.Module):
         per_channel_max = _AbsMaxFn.apply(x, self.stats_reduce_dim, getattr(self, 'bvq_shard_group', None))
         out = torch.norm(per_channel_max, p=2)
         return out / math.sqrt(per_channel_max.view(-1).shape[0])
+
+
+class _AbsMomentsFn(Function):
+    """(mean |x|, unbiased variance of |x|) over the whole input or along `dim`: one streaming read
+    (bvq_abs_moments) instead of abs + mean + var; backward one read + one write (bvq_abs_affine_bwd):
+    dx = sgn(x) * (gmean / n + gvar * 2 (|x| - mean) / (n - 1))"""
+
+    @staticmethod
+    def forward(ctx, x, dim):
+        xc, outer, ch, inner, out_shape = _as_rows(x, dim)
+        n = outer * inner
+        sums = nat.abs_moments(xc.reshape(-1), outer, ch, inner).double()
+        mean = sums[:ch] / n
+        var = (sums[ch:] - sums[:ch] * mean) / (n - 1) if n > 1 else torch.full_like(mean, float('nan'))
+        var = var.clamp_min(0.0)  # rounding of the two sums can leave a tiny negative difference
+        ctx.layout = (outer, ch, inner, dim, n)
+        ctx.save_for_backward(x, mean)
+        return mean.to(x.dtype).reshape(out_shape), var.to(x.dtype).reshape(out_shape)
+
+    @staticmethod
+    def backward(ctx, gmean, gvar):
+        x, mean = ctx.saved_tensors
+        outer, ch, inner, dim, n = ctx.layout
+        xc, _, _, _, _ = _as_rows(x, dim)
+        zero = torch.zeros(ch, dtype=torch.float64, device=x.device)
+        gm = gmean.reshape(-1).double() if gmean is not None else zero
+        gv = gvar.reshape(-1).double() if gvar is not None else zero
+        b = 2.0 * gv / (n - 1) if n > 1 else zero
+        a = gm / n - b * mean
+        dx = nat.abs_affine_bwd(xc.reshape(-1), a.float(), b.float(), outer, ch, inner)
+        return _unrows(dx, x, dim), None
+
+
+class AbsAve(torch.nn.Module):
+    """mean(|x|) over the whole input or along `stats_reduce_dim` (B/core/stats/stats_op.py:186-199)"""
+    bvq_is_stat = True
+
+    def __init__(self, stats_reduce_dim: Optional[int] = None) -> None:
+        super().__init__()
+        self.stats_reduce_dim = stats_reduce_dim
+
+    def forward(self, x: Tensor):
+        return _AbsMomentsFn.apply(x, self.stats_reduce_dim)[0]
+
+
+DEFAULT_STD_DEV_EPSILON = 1e-8
+
+
+class _MeanSigmaStdImpl(torch.nn.Module):
+    """mean(|x|) + sigma * sqrt(var(|x|) + eps) (B/core/stats/stats_op.py:219-240)"""
+
+    def __init__(self, stats_reduce_dim: Optional[int] = None, std_dev_epsilon: float = DEFAULT_STD_DEV_EPSILON):
+        super().__init__()
+        self.stats_reduce_dim = stats_reduce_dim
+        self.epsilon = std_dev_epsilon
+
+    def forward(self, x: Tensor, sigma: Tensor):
+        mean_val, var_val = _AbsMomentsFn.apply(x, self.stats_reduce_dim)
+        std_val = torch.sqrt(var_val + self.epsilon)
+        if self.stats_reduce_dim is not None:
+            mean_val = mean_val.view(-1)
+            std_val = std_val.view(-1)
+        return mean_val + sigma * std_val
+
+
+class MeanSigmaStd(torch.nn.Module):
+    bvq_is_stat = True
+
+    def __init__(self, sigma: float, stats_reduce_dim: Optional[int] = None,
+                 std_dev_epsilon: float = DEFAULT_STD_DEV_EPSILON) -> None:
+        super().__init__()
+        from brevitas_amd.core.utils import StatelessBuffer
+        self.impl = _MeanSigmaStdImpl(stats_reduce_dim, std_dev_epsilon)
+        self.sigma = StatelessBuffer(torch.tensor(sigma))
+
+    def forward(self, x: Tensor):
+        return self.impl(x, self.sigma())
+
+
+class MeanLearnedSigmaStd(torch.nn.Module):
+    """MeanSigmaStd with a learned sigma (B/core/stats/stats_op.py:243-279).  The reference snapshot
+    registers the parameter as `value` but reads `self.sigma` in forward and in its state-dict hook; the
+    name used consistently here is `sigma` (with the reference's `learned_sigma` retro-compatibility key)."""
+    bvq_is_stat = True
+
+    def __init__(self, sigma: float, stats_output_shape, stats_reduce_dim: Optional[int] = None,
+                 std_dev_epsilon: float = DEFAULT_STD_DEV_EPSILON) -> None:
+        super().__init__()
+        self.impl = _MeanSigmaStdImpl(stats_reduce_dim, std_dev_epsilon)
+        if tuple(stats_output_shape) == ():
+            self.sigma = torch.nn.Parameter(torch.tensor(sigma))
+        else:
+            self.sigma = torch.nn.Parameter(torch.full(stats_output_shape, sigma))
+
+    def forward(self, x: Tensor):
+        return self.impl(x, self.sigma.view(self.sigma.shape))
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        import brevitas_amd.config as config
+        value_key = prefix + 'sigma'
+        retrocomp_value_key = prefix + 'learned_sigma'
+        if retrocomp_value_key in state_dict:
+            state_dict[value_key] = state_dict.pop(retrocomp_value_key)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+        if config.IGNORE_MISSING_KEYS and value_key in missing_keys:
+            missing_keys.remove(value_key)

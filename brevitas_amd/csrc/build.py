@@ -22,7 +22,7 @@ OBJ_DIR = os.path.join(ROOT, 'build', 'bvq')
 SOURCES = [('bvq_common.hip', [], 'bvq_common.o'), ('bvq_elementwise.hip', [], 'bvq_elementwise.o'),
            ('bvq_stats.hip', [], 'bvq_stats.o'), ('bvq_select.hip', [], 'bvq_select.o'), ('bvq_fakequant.hip', ['BVQ_PART=1'], 'bvq_fakequant_fwd.o'),
            ('bvq_fakequant.hip', ['BVQ_PART=2'], 'bvq_fakequant_bwd.o')]
-HEADERS = ['bvq_common.h', 'bvq_quant_math.h', 'bvq_ties.h', os.path.join(ROOT, 'include', 'bvq.h')]
+HEADERS = ['bvq_common.h', 'bvq_quant_math.h', 'bvq_ties.h', 'bvq_sums.h', os.path.join(ROOT, 'include', 'bvq.h')]
 
 # -ffp-contract=off: the reference rounds after every op; a contracted mul+add would not.
 # hipcc's default fp32 division is correctly rounded (no -ffast-math, no approximate reciprocal).

@@ -70,6 +70,15 @@ int max_units_per_channel() {
   return v;
 }
 
+static int max_rows_per_unit() {
+  static int v = [] {
+    const char* e = getenv("BVQ_MAX_RPU");  // experiments only
+    const int n = e ? atoi(e) : 0;
+    return (n >= 1 && n <= 64) ? n : 64;
+  }();
+  return v;
+}
+
 Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, int64_t unit_cap) {
   Tiling t;
   t.outer = outer;
@@ -98,7 +107,7 @@ Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, in
       const int64_t cap_chunks = 8 * (int64_t)default_piece_chunks() * kWave;
       int64_t best = 1;
       double best_eff = 0.0;
-      for (int64_t r = 1; r <= outer && r <= 64 && r * cpr <= cap_chunks; ++r) {
+      for (int64_t r = 1; r <= outer && r <= max_rows_per_unit() && r * cpr <= cap_chunks; ++r) {
         const int64_t loads = (r * cpr + kWave - 1) / kWave;
         const double eff = (double)(r * cpr) / (double)(loads * kWave);
         if (eff > best_eff + 1e-9) {

@@ -8,6 +8,7 @@
 //   forward  sizeof(x) + sizeof(y)          backward  sizeof(g) + sizeof(x) + sizeof(dx).
 #include "bvq_quant_math.h"
 #include "bvq_ties.h"
+#include "bvq_sums.h"
 
 namespace bvq {
 
@@ -394,67 +395,6 @@ __global__ __launch_bounds__(kBlock) void fakequant_bwd_kernel(QuantArgs a) {
 #undef BVQ_BWD_UNIT
 }
 
-// Combine per-unit partial sums of one channel in a fixed order (double accumulation):
-// channel c owns units (ob*channels + c)*ppr + p for ob in [0, nob), p in [0, ppr).
-// grid = (channels, splits).  splits == 1: the workgroup sums everything and writes the float result.
-// A per-tensor quantizer of a large activation has ~10^5 partials in its one channel; there the range is
-// cut into slices whose double sums go to mid0/mid1[c * splits + s], and a second launch (PT = double,
-// nob = 1, ppr = splits) finishes.  The order of additions is fixed either way: same bits on every run.
-constexpr int64_t kSumSlice = 4096;
-
-static inline int32_t sum_splits(int64_t partials_per_channel) {
-  const int64_t s = (partials_per_channel + kSumSlice - 1) / kSumSlice;
-  return (int32_t)(s < 1 ? 1 : s);
-}
-
-template <typename PT>
-__global__ __launch_bounds__(kBlock) void channel_sum_kernel(const PT* __restrict__ part0,
-                                                             const PT* __restrict__ part1,
-                                                             float* __restrict__ out0,
-                                                             float* __restrict__ out1, int64_t nob,
-                                                             int32_t channels, int64_t ppr,
-                                                             double* __restrict__ mid0,
-                                                             double* __restrict__ mid1) {
-  __shared__ double sh[2][kBlock];
-  const int32_t c = blockIdx.x;
-  const int64_t n = nob * ppr;
-  const int64_t slice = (n + gridDim.y - 1) / gridDim.y;
-  const int64_t k0 = (int64_t)blockIdx.y * slice;
-  const int64_t k1 = k0 + slice < n ? k0 + slice : n;
-  double acc0 = 0.0, acc1 = 0.0;
-  for (int64_t k = k0 + threadIdx.x; k < k1; k += kBlock) {
-    int64_t unit;
-    if (nob == 1) {
-      unit = (int64_t)c * ppr + k;
-    } else {
-      const int64_t o = k / ppr, p = k - o * ppr;
-      unit = (o * channels + c) * ppr + p;
-    }
-    if (part0) acc0 += (double)part0[unit];
-    if (part1) acc1 += (double)part1[unit];
-  }
-  sh[0][threadIdx.x] = acc0;
-  sh[1][threadIdx.x] = acc1;
-  __syncthreads();
-  for (int st = kBlock / 2; st > 0; st >>= 1) {
-    if ((int)threadIdx.x < st) {
-      sh[0][threadIdx.x] += sh[0][threadIdx.x + st];
-      sh[1][threadIdx.x] += sh[1][threadIdx.x + st];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    if (mid0) {
-      const int64_t slot = (int64_t)c * gridDim.y + blockIdx.y;
-      mid0[slot] = sh[0][0];
-      mid1[slot] = sh[1][0];
-    } else {
-      if (out0) out0[c] = (float)sh[0][0];
-      if (out1) out1[c] = (float)sh[1][0];
-    }
-  }
-}
-
 #endif  // backward part
 
 // ------------------------------------------------------------------------------------------------
@@ -669,7 +609,7 @@ extern "C" int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* d) {
   int32_t channels;
   rows_of(d, outer, row_len, channels);
   const int64_t units = bwd_units(d);
-  const int64_t mid = 2 * (int64_t)channels * sum_splits(units / channels + 1) * (int64_t)sizeof(double);
+  const int64_t mid = channel_sums_mid_bytes(units / channels + 1, channels) + 16;
   return 2 * units * (int64_t)sizeof(float) + mid + 256;
 }
 
@@ -714,13 +654,11 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3), full);
   QuantArgs a = {};
   a.t = make_tiling(outer, channels, row_len, vec);
-  int32_t splits = 1;
   int64_t mid_off = 0;
   if (need_sums) {
-    splits = sum_splits(a.t.nob * a.t.ppr);
     // float partials (8-byte aligned end), then the doubles of a split reduction
     mid_off = ((2 * a.t.units * (int64_t)sizeof(float) + 7) / 8) * 8;
-    const int64_t need = mid_off + (splits > 1 ? 2 * (int64_t)channels * splits * (int64_t)sizeof(double) : 0);
+    const int64_t need = mid_off + channel_sums_mid_bytes(a.t.nob * a.t.ppr, channels);
     if (!workspace || workspace_bytes < need) {
       set_error("bvq_fakequant_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes,
                 (long long)need);
@@ -746,19 +684,8 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   rc = check_launch("bvq_fakequant_bwd");
   if (rc) return rc;
   if (need_sums) {
-    const float* p0 = dscale ? a.ds_part : nullptr;
-    const float* p1 = dzp ? a.dzp_part : nullptr;
-    if (splits > 1) {
-      double* mid0 = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + mid_off);
-      double* mid1 = mid0 + (int64_t)channels * splits;
-      channel_sum_kernel<float><<<dim3((unsigned)channels, (unsigned)splits), dim3(kBlock), 0, st>>>(
-          p0, p1, nullptr, nullptr, a.t.nob, channels, a.t.ppr, mid0, mid1);
-      channel_sum_kernel<double><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(
-          dscale ? mid0 : nullptr, dzp ? mid1 : nullptr, dscale, dzp, 1, channels, splits, nullptr, nullptr);
-    } else {
-      channel_sum_kernel<float><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(
-          p0, p1, dscale, dzp, a.t.nob, channels, a.t.ppr, nullptr, nullptr);
-    }
+    launch_channel_sums(dscale ? a.ds_part : nullptr, dzp ? a.dzp_part : nullptr, dscale, dzp, a.t.nob, channels,
+                        a.t.ppr, reinterpret_cast<char*>(workspace) + mid_off, st);
     rc = check_launch("bvq_fakequant_bwd/channel_sum");
   }
   return rc;

@@ -13,6 +13,7 @@
 
 #include "bvq_common.h"
 #include "bvq_ties.h"
+#include "bvq_sums.h"
 
 namespace bvq {
 
@@ -112,6 +113,89 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(StatArgs a) {
     // torch.max / torch.min propagate NaN
     a.part_a[u.id] = nan ? 0x7fc00000u : __builtin_bit_cast(uint32_t, mx);
     a.part_b[u.id] = nan ? 0x7fc00000u : __builtin_bit_cast(uint32_t, mn);
+  }
+}
+
+// ---- first and second moment of |x| (AbsAve, MeanSigmaStd, B/core/stats/stats_op.py:186-262) -------
+// One streaming read: per-unit float32 partial sums of |x| and x^2 (a lane adds ~64 values, the wave
+// reduce and everything after it run in double), combined by the fixed-order channel sums.
+template <typename T, int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void absmoments_kernel(StatArgs a) {
+  const Unit u = locate_unit(a.t);
+  if (!u.valid) return;
+  const int lane = threadIdx.x & 63;
+  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + u.base;
+  float s1 = 0.f, s2 = 0.f;
+  ChunkCursor cur;
+  cur.init(u, VEC, lane);
+  const int64_t total = (int64_t)u.nrows * cur.cpr;
+  for (int64_t done = 0; done < total; done += (int64_t)kWave * kStatUnroll) {
+    vec_t<T, VEC> xv[kStatUnroll];
+    bool ok[kStatUnroll];
+#pragma unroll
+    for (int j = 0; j < kStatUnroll; ++j) {
+      ok[j] = cur.valid();
+      if (ok[j]) xv[j] = load_vec<T, VEC, NT>(xp + cur.offset(u.row_stride, VEC));
+      cur.next();
+    }
+#pragma unroll
+    for (int j = 0; j < kStatUnroll; ++j) {
+      if (ok[j]) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const float f = fabsf(to_f<T>(xv[j].v[k]));
+          s1 += f;
+          s2 += f * f;
+        }
+      }
+    }
+  }
+  const int64_t i = (int64_t)cur.cpr * VEC + lane;
+  if (u.nrows == 1 && i < u.len) {
+    const float f = fabsf(to_f<T>(xp[i]));
+    s1 += f;
+    s2 += f * f;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    a.part_a[u.id] = __builtin_bit_cast(uint32_t, s1);
+    a.part_b[u.id] = __builtin_bit_cast(uint32_t, s2);
+  }
+}
+
+// dx = sgn(x) * (a[c] + b[c] * |x|): the backward of any statistic that is a function of the mean and the
+// variance of |x| (sgn(0) = 0, torch.abs's subgradient)
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void abs_affine_bwd_kernel(Tiling t, const void* x, const float* ca,
+                                                                const float* cb, void* dx) {
+  const Unit u = locate_unit(t);
+  if (!u.valid) return;
+  const int lane = threadIdx.x & 63;
+  const T* __restrict__ xp = reinterpret_cast<const T*>(x) + u.base;
+  T* __restrict__ dp = reinterpret_cast<T*>(dx) + u.base;
+  const float a = ca[u.channel], b = cb[u.channel];
+  auto f = [a, b](T v) -> T {
+    const float xf = to_f<T>(v);
+    const float m = a + b * fabsf(xf);
+    return from_f<T>(xf > 0.f ? m : (xf < 0.f ? -m : (xf == 0.f ? 0.f : xf)));  // NaN in, NaN out
+  };
+  ChunkCursor cur;
+  cur.init(u, VEC, lane);
+  const int64_t total = (int64_t)u.nrows * cur.cpr;
+  for (int64_t done = 0; done < total; done += kWave) {
+    if (cur.valid()) {
+      const int64_t off = cur.offset(u.row_stride, VEC);
+      const vec_t<T, VEC> xv = load_vec<T, VEC>(xp + off);
+      vec_t<T, VEC> dv;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) dv.v[k] = f(xv.v[k]);
+      store_vec<T, VEC>(dp + off, dv);
+    }
+    cur.next();
+  }
+  if (u.nrows == 1 && lane == 0) {
+    for (int64_t e = (int64_t)cur.cpr * VEC; e < u.len; ++e) dp[e] = f(xp[e]);
   }
 }
 
@@ -670,6 +754,104 @@ extern "C" int bvq_absmax_scale(int pre_op, int dtype, const void* x, int64_t ou
   ep.int_threshold = (float)int_threshold;
   return stats_impl(BVQ_STAT_ABSMAX, pre_op, dtype, x, outer, channels, inner, dtype, stat_out, ep, workspace,
                     workspace_bytes, stream);
+}
+
+extern "C" int64_t bvq_abs_moments_workspace_bytes(int dtype, int64_t outer, int64_t channels, int64_t inner) {
+  if (bad_dtype(dtype) || outer < 0 || channels < 1 || inner < 0) return -1;
+  const int64_t units = worst_units(dtype, outer, channels, inner);
+  return 2 * units * (int64_t)sizeof(float) + 8 + channel_sums_mid_bytes(units / channels + 1, channels) + 256;
+}
+
+extern "C" int bvq_abs_moments(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+                               float* sums, void* workspace, int64_t workspace_bytes, bvq_stream_t stream) {
+  if (bad_dtype(dtype) || outer < 0 || channels < 1 || inner < 0) {
+    set_error("bvq_abs_moments: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  if (!sums) {
+    set_error("bvq_abs_moments: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = outer * channels * inner;
+  if (n == 0) {  // an empty sum
+    (void)hipMemsetAsync(sums, 0, 2 * sizeof(float) * channels, st);
+    return BVQ_OK;
+  }
+  if (!x || !workspace) {
+    set_error("bvq_abs_moments: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  int vec;
+  StatArgs a;
+  a.t = stat_tiling(dtype, x, nullptr, outer, channels, inner, vec);
+  const int64_t mid_off = ((2 * a.t.units * (int64_t)sizeof(float) + 7) / 8) * 8;
+  const int64_t need = mid_off + channel_sums_mid_bytes(a.t.nob * a.t.ppr, channels);
+  if (workspace_bytes < need) {
+    set_error("bvq_abs_moments: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    return BVQ_ERR_WORKSPACE;
+  }
+  a.x = x;
+  a.part_a = reinterpret_cast<uint32_t*>(workspace);
+  a.part_b = a.part_a + a.t.units;
+  const bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
+  const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
+#define BVQ_MOM(T)                                                     \
+  do {                                                                 \
+    constexpr int V = elem<T>::vec;                                    \
+    if (vec == V && nt)                                                \
+      absmoments_kernel<T, V, true><<<grid, block, 0, st>>>(a);        \
+    else if (vec == V)                                                 \
+      absmoments_kernel<T, V, false><<<grid, block, 0, st>>>(a);       \
+    else                                                               \
+      absmoments_kernel<T, 1, false><<<grid, block, 0, st>>>(a);       \
+  } while (0)
+  if (dtype == BVQ_F32)
+    BVQ_MOM(float);
+  else if (dtype == BVQ_BF16)
+    BVQ_MOM(bf16_t);
+  else
+    BVQ_MOM(f16_t);
+#undef BVQ_MOM
+  int rc = check_launch("bvq_abs_moments");
+  if (rc) return rc;
+  launch_channel_sums(reinterpret_cast<const float*>(a.part_a), reinterpret_cast<const float*>(a.part_b), sums,
+                      sums + channels, a.t.nob, (int32_t)channels, a.t.ppr,
+                      reinterpret_cast<char*>(workspace) + mid_off, st);
+  return check_launch("bvq_abs_moments/sums");
+}
+
+extern "C" int bvq_abs_affine_bwd(int dtype, const void* x, const float* a, const float* b, void* dx,
+                                  int64_t outer, int64_t channels, int64_t inner, bvq_stream_t stream) {
+  if (bad_dtype(dtype) || outer < 0 || channels < 1 || inner < 0) {
+    set_error("bvq_abs_affine_bwd: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  if (outer * channels * inner == 0) return BVQ_OK;
+  if (!x || !a || !b || !dx) {
+    set_error("bvq_abs_affine_bwd: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int vec;
+  const Tiling t = stat_tiling(dtype, x, dx, outer, channels, inner, vec);
+  const dim3 grid(grid_for_units(t.units)), block(kBlock);
+#define BVQ_AFF(T)                                                               \
+  do {                                                                           \
+    constexpr int V = elem<T>::vec;                                              \
+    if (vec == V)                                                                \
+      abs_affine_bwd_kernel<T, V><<<grid, block, 0, st>>>(t, x, a, b, dx);       \
+    else                                                                         \
+      abs_affine_bwd_kernel<T, 1><<<grid, block, 0, st>>>(t, x, a, b, dx);       \
+  } while (0)
+  if (dtype == BVQ_F32)
+    BVQ_AFF(float);
+  else if (dtype == BVQ_BF16)
+    BVQ_AFF(bf16_t);
+  else
+    BVQ_AFF(f16_t);
+#undef BVQ_AFF
+  return check_launch("bvq_abs_affine_bwd");
 }
 
 extern "C" int bvq_running_stats_update(int run_dtype, void* running, int stat_dtype, const void* stat,

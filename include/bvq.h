@@ -198,6 +198,20 @@ int bvq_absmax_scale(int pre_op, int dtype, const void* x, int64_t outer, int64_
 int bvq_running_stats_update(int run_dtype, void* running, int stat_dtype, const void* stat, int64_t n,
                              double momentum, int first_batch, bvq_stream_t stream);
 
+/* ---- moment statistics ---------------------------------------------------------------------------
+ * sums[c] = SUM |x|, sums[channels + c] = SUM x^2 over the `outer` and `inner` axes, as float32 (per-unit
+ * float32 partials, double accumulation across units, fixed order): what AbsAve (mean |x|) and
+ * MeanSigmaStd / MeanLearnedSigmaStd (mean |x| + sigma * sqrt(var |x| + eps)) need, in ONE read of x
+ * instead of abs (read + write) + mean (read) + var (read) -- B/core/stats/stats_op.py:186-262.  The host
+ * finishes on `channels` values.  Sums are order-dependent: equal to torch's within float32 rounding. */
+int64_t bvq_abs_moments_workspace_bytes(int dtype, int64_t outer, int64_t channels, int64_t inner);
+int bvq_abs_moments(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner, float* sums,
+                    void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
+/* dx = sgn(x) * (a[c] + b[c] * |x|), rounded once to x's dtype: the backward of any function of those two
+ * moments (a = dL/dmean / n - 2 mean dL/dvar / (n-1), b = 2 dL/dvar / (n-1)); sgn(0) = 0 */
+int bvq_abs_affine_bwd(int dtype, const void* x, const float* a, const float* b, void* dx, int64_t outer,
+                       int64_t channels, int64_t inner, bvq_stream_t stream);
+
 /* ---- percentile statistics ---------------------------------------------------------------------
  * k-th smallest value (k is 1-indexed, the same for every channel) of |x| (abs_key = 1) or of x
  * (abs_key = 0) over the `outer` and `inner` axes of x[outer, channels, inner]: torch.kthvalue on the

@@ -153,6 +153,16 @@ def stats(kind, x, dt, outer, channels, inner, pre_op=PRE_NONE):
     return out
 
 
+def abs_moments(x, dt, outer, channels, inner):
+    """-> float64 [2 * channels]: sum |x|, then sum x^2"""
+    x = _c(x, dt)
+    assert x.size == outer * channels * inner
+    out = np.empty(2 * channels, dtype=np.float64)
+    lib().orc_abs_moments(dt, _ptr(x), ctypes.c_int64(outer), ctypes.c_int64(channels), ctypes.c_int64(inner),
+                          _ptr(out))
+    return out
+
+
 def kth_value(x, dt, outer, channels, inner, k, abs_key):
     x = _c(x, dt)
     out = np.empty(channels, dtype=np.float32)

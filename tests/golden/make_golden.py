@@ -747,10 +747,30 @@ def gen_learned_bw():
     st.save()
 
 
+# ------------------------------------------------------------------------------------------------
+# K. moment statistics (B/core/stats/stats_op.py:186-231): AbsAve, MeanSigmaStd
+# ------------------------------------------------------------------------------------------------
+def gen_moments():
+    from brevitas.core.stats import AbsAve, MeanSigmaStd
+    st = Store('moments')
+    for dn in ('f32', 'bf16'):
+        for tag, shape, dim in (('tensor', (2000,), None), ('rows', (7, 300), 1), ('cols', (300, 7), 0)):
+            for name, mk in (('abs_ave', lambda d: AbsAve(d)), ('mean_sigma_std', lambda d: MeanSigmaStd(3.0, d))):
+                x = (torch.randn(shape) * 0.7 + 0.1).to(DT[dn])
+                x.view(-1)[::17] = 0.0
+                xi = x.clone().requires_grad_(True)
+                out = mk(dim)(xi)
+                g = torch.randn(out.shape).to(out.dtype)
+                out.backward(g)
+                st.case({'stat': name, 'tag': tag, 'dim': dim, 'dtype': dn, 'shape': list(shape)}, x=x, out=out, g=g,
+                        dx=xi.grad)
+    st.save()
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     only = sys.argv[1:]
-    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point', 'learned_bw'}:
+    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point', 'learned_bw', 'moments'}:
         # the first four files were generated in ONE run, in this order, from a single seed
         torch.manual_seed(123456)
         gen_ste()
@@ -775,3 +795,6 @@ if __name__ == '__main__':
     if not only or 'learned_bw' in only:
         torch.manual_seed(123462)
         gen_learned_bw()
+    if not only or 'moments' in only:
+        torch.manual_seed(123463)
+        gen_moments()
