@@ -223,7 +223,8 @@ int default_piece_chunks();
 int pick_vec(int max_vec, int64_t rows, int64_t row_len, const void* const* ptrs, const int* elsizes,
              int nptr);
 
-Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, int64_t unit_cap = 0);
+Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, int64_t unit_cap = 0,
+                   bool few_rows = false);
 
 static inline unsigned grid_for_units(int64_t units) {
   return (unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -271,8 +272,48 @@ __device__ __forceinline__ Unit locate_unit(const Tiling& t) {
 }
 
 // Per-lane walk over the VEC-element chunks of a unit: chunk k of the unit (k = lane, lane+64, ...)
-// lives in row k / cpr at chunk k % cpr; the walk advances by 64 chunks without dividing.
+// lives in row k / cpr at chunk k % cpr.  Advancing by 64 chunks is "dq rows and dr chunks, plus a
+// carry" with the wave-uniform dq = 64 / cpr, dr = 64 % cpr: one division per unit, none and no
+// branch per step (a single-row unit is the special case dq = 0, dr = 64).
 struct ChunkCursor {
+  int32_t row;    // row inside the unit
+  int32_t chunk;  // chunk inside the row
+  int32_t cpr;    // full chunks per row
+  int32_t nrows;
+  int32_t dq, dr;
+  __device__ __forceinline__ void init(const Unit& u, int vec, int lane) {
+    cpr = (int32_t)(u.len / vec);
+    nrows = u.nrows;
+    const int32_t c = cpr > 0 ? cpr : 1;
+    dq = kWave / c;
+    dr = kWave - dq * c;
+    const int32_t r0 = lane / c;  // 0 for every lane when a row has >= 64 chunks
+    chunk = lane - r0 * c;
+    // rows shorter than one chunk: nothing to walk (the ragged-end code takes them)
+    row = cpr > 0 ? r0 : nrows;
+  }
+  __device__ __forceinline__ bool valid() const { return row < nrows; }
+  __device__ __forceinline__ void next() {
+    chunk += dr;
+    row += dq;
+    const bool carry = chunk >= cpr;
+    chunk -= carry ? cpr : 0;
+    row += carry ? 1 : 0;
+  }
+  // element offset from the unit's base / from pos0
+  __device__ __forceinline__ int64_t offset(int64_t row_stride, int vec) const {
+    return (int64_t)row * row_stride + (int64_t)chunk * vec;
+  }
+  __device__ __forceinline__ int64_t pos(int64_t row_len, int vec) const {
+    return (int64_t)row * row_len + (int64_t)chunk * vec;
+  }
+};
+
+// The same walk with a loop for the row carry: the form the read-only kernels (statistics, select, tie
+// scan) keep -- measured on MI355X they stream 5-10 % faster with it (their loads are predicated, and a
+// single-row unit, the common case, advances with one add), while the quantizer kernels, which issue
+// their loads unconditionally, are faster with the branch-free ChunkCursor above.
+struct ChunkWalker {
   int32_t row;    // row inside the unit
   int32_t chunk;  // chunk inside the row
   int32_t cpr;    // full chunks per row
@@ -306,6 +347,7 @@ struct ChunkCursor {
     return (int64_t)row * row_len + (int64_t)chunk * vec;
   }
 };
+
 #endif
 
 }  // namespace bvq

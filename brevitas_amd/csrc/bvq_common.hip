@@ -79,7 +79,8 @@ static int max_rows_per_unit() {
   return v;
 }
 
-Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, int64_t unit_cap) {
+Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, int64_t unit_cap,
+                   bool few_rows) {
   Tiling t;
   t.outer = outer;
   t.channels = channels;
@@ -99,8 +100,12 @@ Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, in
       piece = ((piece + quantum - 1) / quantum) * quantum;
     }
   } else {
-    // short rows: one piece per row, several rows of one channel per unit.  Pick the row count that
-    // wastes the fewest lanes of the 64-wide loads, within ~8 pieces worth of work per unit.
+    // short rows: one piece per row, several rows of one channel per unit, within ~8 pieces worth of
+    // work.  The read-only kernels take the row count that wastes the fewest lanes of the 64-wide loads
+    // (long units amortise the per-wave setup).  The quantizer kernels (few_rows) take the FEWEST rows
+    // that keep >= 86 % of the lanes busy: rows of one channel are channels * row_len apart, and with a
+    // store stream next to the loads a unit hopping between them streams measurably worse than one
+    // contiguous row (-8 % on [256,512,56,56] bf16; profiles/r01_microbench_v3.txt).
     piece = row_len > 0 ? ((row_len + vec - 1) / vec) * vec : vec;
     const int64_t cpr = row_len / vec;  // full chunks per row
     if (cpr > 0 && outer > 1) {
@@ -114,6 +119,7 @@ Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, in
           best_eff = eff;
           best = r;
         }
+        if (few_rows && eff >= 0.86) break;
       }
       t.rpu = (int32_t)best;
     }

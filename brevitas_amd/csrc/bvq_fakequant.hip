@@ -36,7 +36,7 @@ struct QuantArgs {
 };
 
 #ifndef BVQ_FWD_UNROLL
-#define BVQ_FWD_UNROLL 4
+#define BVQ_FWD_UNROLL 8
 #endif
 #ifndef BVQ_BWD_UNROLL
 #define BVQ_BWD_UNROLL 2
@@ -63,6 +63,18 @@ __device__ __forceinline__ float do_round(float t, int mode) {
     return round_op<CT, RM>(t);
   }
 }
+template <typename CT, int RM>
+__device__ __forceinline__ f2 do_round2(f2 t, int mode) {
+  if constexpr (RM == kAnyRM) {
+    return round_any2<CT>(t, mode);
+  } else {
+    return round_op2<CT, RM>(t);
+  }
+}
+__device__ __forceinline__ f2 relu2(f2 v) {
+  const f2 zero = splat2(0.f);
+  return v < zero ? zero : v;  // NaN and -0.0 pass through, like relu_f
+}
 
 // ------------------------------------------------------------------------------------------------
 // division by the (wave-uniform) scale
@@ -78,10 +90,15 @@ __device__ __forceinline__ float do_round(float t, int mode) {
 struct DivExact {
   float s;
   __device__ __forceinline__ float operator()(float a) const { return a / s; }
+  __device__ __forceinline__ f2 operator()(f2 a) const {
+    f2 r = {a.x / s, a.y / s};
+    return r;
+  }
 };
 struct DivBf16 {
   float r;
   __device__ __forceinline__ float operator()(float a) const { return a * r; }
+  __device__ __forceinline__ f2 operator()(f2 a) const { return a * r; }
 };
 
 __device__ __forceinline__ bool bf16_scale_ok(float s) {
@@ -113,6 +130,20 @@ __device__ __forceinline__ float fwd_elem(float xf, const Div& div, float s, flo
   q_out = q;
   if (out_int) return q;
   return ZP0 ? rnd<CT>(q * s) : rnd<CT>(rnd<CT>(q - z) * s);  // (y_int - zero_point) * scale :93-94
+}
+
+// fwd_elem on a pair of elements (bvq_quant_math.h: packed fp32 / packed bf16 conversion)
+template <typename CT, int RM, bool ZP0, typename Div>
+__device__ __forceinline__ f2 fwd_elem2(f2 xf, const Div& div, float s, float z, float qmin, float qmax,
+                                        bool out_int, int mode, f2& q_out) {
+  f2 t = rnd2<CT>(div(xf));
+  t = ZP0 ? t + 0.f : rnd2<CT>(t + z);
+  t = do_round2<CT, RM>(t, mode);
+  const f2 q = clamp_where2(t, qmin, qmax);
+  q_out = q;
+  if (out_int) return q;
+  // the last rounding to CT is the caller's pack2<CT> (one v_cvt_pk_bf16_f32 for the pair)
+  return ZP0 ? q * s : rnd2<CT>(q - z) * s;  // (y_int - zero_point) * scale :93-94
 }
 
 // store VEC integer codes (parity / export mode): int32, int8 or uint8
@@ -157,7 +188,7 @@ __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, cons
     for (int j = 0; j < kUnroll; ++j) {
       ok[j] = cur.valid();
       off[j] = cur.offset(u.row_stride, VEC);
-      if (ok[j]) xv[j] = load_vec<XT, VEC, NT>(xp + off[j]);
+      xv[j] = load_vec<XT, VEC, NT>(xp + (ok[j] ? off[j] : 0));  // past the end: re-read the unit's first chunk
       cur.next();
     }
 #pragma unroll
@@ -165,11 +196,24 @@ __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, cons
       if (ok[j]) {
         vec_t<CT, VEC> yv;
         float qv[VEC];
+        if constexpr (VEC % 2 == 0) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-          const float xf = PRE ? relu_f(to_f<XT>(xv[j].v[k])) : to_f<XT>(xv[j].v[k]);
-          const float r = fwd_elem<CT, RM, ZP0>(xf, div, s, z, qmin, qmax, out_int, mode, qv[k]);
-          yv.v[k] = from_f<CT>(r);
+          for (int k = 0; k < VEC; k += 2) {
+            f2 xf = widen2<XT>(xv[j].v[k], xv[j].v[k + 1]);
+            if constexpr (PRE) xf = relu2(xf);
+            f2 q2;
+            const f2 r = fwd_elem2<CT, RM, ZP0>(xf, div, s, z, qmin, qmax, out_int, mode, q2);
+            pack2<CT>(r, yv.v[k], yv.v[k + 1]);
+            qv[k] = q2.x;
+            qv[k + 1] = q2.y;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const float xf = PRE ? relu_f(to_f<XT>(xv[j].v[k])) : to_f<XT>(xv[j].v[k]);
+            const float r = fwd_elem<CT, RM, ZP0>(xf, div, s, z, qmin, qmax, out_int, mode, qv[k]);
+            yv.v[k] = from_f<CT>(r);
+          }
         }
         if (yp) store_vec<CT, VEC, NT>(yp + off[j], yv);
         if (cp) store_codes<VEC>(cp, a.codes_dtype, u.base + off[j], qv);  // parity / export mode only
@@ -268,6 +312,36 @@ __device__ __forceinline__ float bwd_elem(float xf, float gf, const Div& div, fl
   return dxv;
 }
 
+// bwd_elem on a pair of elements; the sums are kept as pairs too (added up once per unit)
+template <typename CT, int RM, int MODE, bool ZP0, bool SAME16, typename Div>
+__device__ __forceinline__ f2 bwd_elem2(f2 xf, f2 gf, const Div& div, float s, float z, float qmin, float qmax,
+                                        bool clamp_ste, int mode, f2& ds_acc, f2& dzp_acc) {
+  const f2 t1 = rnd2<CT>(div(xf));
+  const f2 t2 = ZP0 ? t1 + 0.f : rnd2<CT>(t1 + z);
+  const f2 t3 = do_round2<CT, RM>(t2, mode);
+  const f2 qhi = splat2(qmax), qlo = splat2(qmin);
+  const b2 hi = t3 > qhi;
+  f2 t4 = hi ? qhi : t3;
+  const b2 lo = t4 < qlo;
+  t4 = lo ? qlo : t4;
+  const b2 all = {-1, -1};
+  const b2 pass = clamp_ste ? all : ~(hi | lo);
+  const f2 gs = rnd2<CT>(gf * s);
+  const f2 dt = pass ? gs : splat2(0.f);
+  // rounded to CT, then stored as XT by the caller's pack2: when both are the same 16-bit type that second
+  // conversion IS the rounding (rounding twice to one grid changes nothing), so it is not done here
+  const f2 dxv = SAME16 ? div(dt) : rnd2<CT>(div(dt));
+  if constexpr (MODE >= kBwdDs) {
+    const f2 t5 = ZP0 ? t4 : rnd2<CT>(t4 - z);
+    const f2 term1 = rnd2<CT>(gf * t5);
+    const f2 term2 = rnd2<CT>(-dt * rnd2<CT>(div(t1)));
+    ds_acc += term1;
+    ds_acc += term2;
+  }
+  if constexpr (MODE == kBwdDsDzp) dzp_acc += dt - gs;
+  return dxv;
+}
+
 template <typename XT, typename CT, int VEC, int RM, int MODE, bool NT, bool ZP0, bool PRE, typename Div>
 __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, const Div& div, float s,
                                          float z, float qmin, float qmax) {
@@ -285,6 +359,8 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
     stat_bits = abs_bits<XT>(reinterpret_cast<const XT*>(a.tie_stat)[u.channel]);
 
   float ds_acc = 0.f, dzp_acc = 0.f;
+  uint32_t umax = 0;  // kBwdDsTies: largest |x| key this lane has seen in the unit's full chunks
+  f2 ds_acc2 = splat2(0.f), dzp_acc2 = splat2(0.f);  // pairwise path; folded into the scalars at the end
   constexpr int kU = kBwdUnroll;  // chunks per lane in flight, for each of the two input streams
   ChunkCursor cur;
   cur.init(u, VEC, lane);
@@ -293,45 +369,79 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
     vec_t<XT, VEC> xv[kU];
     vec_t<CT, VEC> gv[kU];
     int64_t off[kU];
-    int64_t pos[kU];
     bool ok[kU];
 #pragma unroll
     for (int j = 0; j < kU; ++j) {
       ok[j] = cur.valid();
       off[j] = cur.offset(u.row_stride, VEC);
-      if constexpr (MODE == kBwdDsTies) pos[j] = u.pos0 + cur.pos(a.t.row_len, VEC);
-      if (ok[j]) {
-        xv[j] = load_vec<XT, VEC, NT>(xp + off[j]);
-        gv[j] = load_vec<CT, VEC, NT>(gp + off[j]);
-      }
+      const int64_t lo = ok[j] ? off[j] : 0;  // past the end: re-read the unit's first chunk
+      xv[j] = load_vec<XT, VEC, NT>(xp + lo);
+      gv[j] = load_vec<CT, VEC, NT>(gp + lo);
       cur.next();
     }
 #pragma unroll
     for (int j = 0; j < kU; ++j) {
       if (ok[j]) {
         vec_t<XT, VEC> dv;
-        uint32_t mx = 0;
+        if constexpr (VEC % 2 == 0) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-          const float xraw = to_f<XT>(xv[j].v[k]);
-          float d = bwd_elem<CT, RM, MODE, ZP0>(PRE ? relu_f(xraw) : xraw, to_f<CT>(gv[j].v[k]), div, s, z,
-                                                qmin, qmax, clamp_ste, mode, ds_acc, dzp_acc);
-          if constexpr (PRE) d = xraw > 0.f ? d : 0.f;  // torch.relu backward: grad * (x > 0)
-          dv.v[k] = from_f<XT>(d);
-          if constexpr (MODE == kBwdDsTies) {
-            // cheap chunk-level filter: a tie in this chunk needs the chunk's max |x| to reach the statistic
-            const uint32_t b = pre_abs_bits<XT, PRE>(xv[j].v[k]);
-            mx = b > mx ? b : mx;
+          for (int k = 0; k < VEC; k += 2) {
+            const f2 xraw = widen2<XT>(xv[j].v[k], xv[j].v[k + 1]);
+            constexpr bool kSame16 = sizeof(CT) == 2 && sizeof(XT) == 2;  // then XT is CT (dispatch pairs)
+            f2 d = bwd_elem2<CT, RM, MODE, ZP0, kSame16>(PRE ? relu2(xraw) : xraw, widen2<CT>(gv[j].v[k], gv[j].v[k + 1]),
+                                                div, s, z, qmin, qmax, clamp_ste, mode, ds_acc2, dzp_acc2);
+            if constexpr (PRE) d = xraw > splat2(0.f) ? d : splat2(0.f);  // torch.relu backward: grad * (x > 0)
+            pack2<XT>(d, dv.v[k], dv.v[k + 1]);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const float xraw = to_f<XT>(xv[j].v[k]);
+            float d = bwd_elem<CT, RM, MODE, ZP0>(PRE ? relu_f(xraw) : xraw, to_f<CT>(gv[j].v[k]), div, s, z,
+                                                  qmin, qmax, clamp_ste, mode, ds_acc, dzp_acc);
+            if constexpr (PRE) d = xraw > 0.f ? d : 0.f;  // torch.relu backward: grad * (x > 0)
+            dv.v[k] = from_f<XT>(d);
+          }
+        }
+        if constexpr (MODE == kBwdDsTies) {
+          // cheap chunk-level filter: a tie in this chunk needs the chunk's max |x| to reach the statistic
+          if constexpr (sizeof(XT) == 2 && VEC % 2 == 0 && !PRE) {
+            // two 16-bit keys per word: clear both sign bits, packed unsigned max (2 ops per pair)
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            const vec_t<uint32_t, VEC / 2> w = __builtin_bit_cast(vec_t<uint32_t, VEC / 2>, xv[j]);
+            u16x2 m2 = {0, 0};
+#pragma unroll
+            for (int k = 0; k < VEC / 2; ++k)
+              m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, w.v[k] & 0x7fff7fffu));
+            const uint32_t m16 = m2.x > m2.y ? m2.x : m2.y;
+            const uint32_t mx = elem<XT>::id == BVQ_BF16 ? (m16 << 16) : m16;  // the abs_bits<> key space
+            umax = mx > umax ? mx : umax;
+          } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+              const uint32_t b = pre_abs_bits<XT, PRE>(xv[j].v[k]);
+              umax = b > umax ? b : umax;
+            }
           }
         }
         store_vec<XT, VEC, NT>(dxp + off[j], dv);
-        if constexpr (MODE == kBwdDsTies) {
-          if (mx >= stat_bits) {  // rare: a handful of elements per channel attain the maximum
-            for (int k = 0; k < VEC; ++k)
-              if (pre_abs_bits<XT, PRE>(xv[j].v[k]) == stat_bits)
-                record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(pos[j] + k));
-          }
-        }
+      }
+    }
+  }
+  if constexpr (MODE == kBwdDsTies) {
+    // Rare: a handful of elements per channel attain the maximum.  The hot loop only tracked this lane's
+    // largest key; a lane that saw the statistic walks its chunks once more (cold code, out of the hot
+    // loop's register budget) and records the positions.
+    if (umax >= stat_bits) {
+      ChunkCursor c2;
+      c2.init(u, VEC, lane);
+      while (c2.valid()) {
+        const vec_t<XT, VEC> xr = load_vec<XT, VEC>(xp + c2.offset(u.row_stride, VEC));
+        const int64_t pos = u.pos0 + c2.pos(a.t.row_len, VEC);
+        for (int k = 0; k < VEC; ++k)
+          if (pre_abs_bits<XT, PRE>(xr.v[k]) == stat_bits)
+            record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(pos + k));
+        c2.next();
       }
     }
   }
@@ -348,6 +458,8 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
     }
   }
   if constexpr (MODE >= kBwdDs) {
+    ds_acc += ds_acc2.x + ds_acc2.y;
+    dzp_acc += dzp_acc2.x + dzp_acc2.y;
     ds_acc = wave_sum(ds_acc);
     if (lane == 0) a.ds_part[u.id] = ds_acc;
     if constexpr (MODE == kBwdDsDzp) {
@@ -574,7 +686,7 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
   const int full = 16 / dtype_size(d->x_dtype);
   const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3), full);
   QuantArgs a = {};
-  a.t = make_tiling(outer, channels, row_len, vec);
+  a.t = make_tiling(outer, channels, row_len, vec, 0, true);
   a.x = x;
   a.scale = scale;
   a.zp = zp;
@@ -598,8 +710,8 @@ static int64_t bwd_units(const bvq_quant_desc* d) {
   rows_of(d, outer, row_len, channels);
   // upper bound over the vector widths the launcher may pick
   const int full = 16 / dtype_size(d->x_dtype);
-  const int64_t a = make_tiling(outer, channels, row_len, full).units;
-  const int64_t b = make_tiling(outer, channels, row_len, 1).units;
+  const int64_t a = make_tiling(outer, channels, row_len, full, 0, true).units;
+  const int64_t b = make_tiling(outer, channels, row_len, 1, 0, true).units;
   return a > b ? a : b;
 }
 
@@ -653,7 +765,7 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   const int full = 16 / dtype_size(d->x_dtype);
   const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3), full);
   QuantArgs a = {};
-  a.t = make_tiling(outer, channels, row_len, vec);
+  a.t = make_tiling(outer, channels, row_len, vec, 0, true);
   int64_t mid_off = 0;
   if (need_sums) {
     // float partials (8-byte aligned end), then the doubles of a split reduction

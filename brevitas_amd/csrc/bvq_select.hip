@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void kth_hist_kernel(SelArgs a) {
   const uint32_t want = a.first_pass ? 0u : a.prefix[u.channel];
   const int hi_shift = a.shift + a.bits;  // bits above this pass's digit
   const uint32_t mask = (1u << a.bits) - 1u;
-  ChunkCursor cur;
+  ChunkWalker cur;
   cur.init(u, VEC, lane);
   const int64_t total = (int64_t)u.nrows * cur.cpr;
   for (int64_t done = 0; done < total; done += (int64_t)kWave * kSelUnroll) {

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void absmax_kernel(StatArgs a) {
   const int lane = threadIdx.x & 63;
   const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + u.base;
   uint32_t m = 0;
-  ChunkCursor cur;
+  ChunkWalker cur;
   cur.init(u, VEC, lane);
   const int64_t total = (int64_t)u.nrows * cur.cpr;
   for (int64_t done = 0; done < total; done += (int64_t)kWave * kStatUnroll) {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(StatArgs a) {
   const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + u.base;
   float mx = -__builtin_inff(), mn = __builtin_inff();
   uint32_t nan = 0;
-  ChunkCursor cur;
+  ChunkWalker cur;
   cur.init(u, VEC, lane);
   const int64_t total = (int64_t)u.nrows * cur.cpr;
   for (int64_t done = 0; done < total; done += (int64_t)kWave * kStatUnroll) {
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void absmoments_kernel(StatArgs a) {
   const int lane = threadIdx.x & 63;
   const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + u.base;
   float s1 = 0.f, s2 = 0.f;
-  ChunkCursor cur;
+  ChunkWalker cur;
   cur.init(u, VEC, lane);
   const int64_t total = (int64_t)u.nrows * cur.cpr;
   for (int64_t done = 0; done < total; done += (int64_t)kWave * kStatUnroll) {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void abs_affine_bwd_kernel(Tiling t, const 
     const float m = a + b * fabsf(xf);
     return from_f<T>(xf > 0.f ? m : (xf < 0.f ? -m : (xf == 0.f ? 0.f : xf)));  // NaN in, NaN out
   };
-  ChunkCursor cur;
+  ChunkWalker cur;
   cur.init(u, VEC, lane);
   const int64_t total = (int64_t)u.nrows * cur.cpr;
   for (int64_t done = 0; done < total; done += kWave) {
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void tie_scan_kernel(Tiling t, const void* 
   T* __restrict__ dp = reinterpret_cast<T*>(dx) + u.base;
   const T sv = reinterpret_cast<const T*>(stat)[u.channel];
   const bool per_channel = t.channels > 1 || first_only;  // record the first position only
-  ChunkCursor cur;
+  ChunkWalker cur;
   cur.init(u, VEC, lane);
   const int64_t total = (int64_t)u.nrows * cur.cpr;
   for (int64_t done = 0; done < total; done += kWave) {

@@ -49,6 +49,9 @@ def main():
             print('%s fwd    %-11s %.3f ms  %.2f TB/s' % (name, tag, t, 2 * b * n / t / 1e9))
             t = timeit(lambda: nat.fakequant_bwd(d, g, x, scale, zp, True, False))
             print('%s bwd    %-11s %.3f ms  %.2f TB/s (with dscale)' % (name, tag, t, 3 * b * n / t / 1e9))
+            t = timeit(lambda: nat.fakequant_bwd(d, g, x, scale, zp, True, False, tie_stat=stat))
+            print('%s bwd    %-11s %.3f ms  %.2f TB/s (with dscale + arg-max search: the stats-scaled graph)' % (
+                name, tag, t, 3 * b * n / t / 1e9))
             t = timeit(lambda: nat.fakequant_bwd(d, g, x, scale, zp, False, False))
             print('%s bwd    %-11s %.3f ms  %.2f TB/s (dx only)' % (name, tag, t, 3 * b * n / t / 1e9))
         del x, g, y
