@@ -1,0 +1,78 @@
+"""The quantizer steps are capturable in a HIP graph (torch.cuda.CUDAGraph): every launch goes to the
+current stream, nothing is read back to the host, all scratch comes from torch's (graph-aware) allocator.
+A captured forward + backward of a weight quantizer and of a stats-scaled activation quantizer must replay
+to the same bits as the eager step, also after the inputs changed in place."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _capture(step_fn):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step_fn()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step_fn()
+    return graph, out
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_weight_quantizer_step_in_a_graph(dtype):
+    import brevitas_amd.quant as Q
+    torch.manual_seed(123456)
+    w = torch.nn.Parameter((torch.randn(64, 32, 3, 3, device=DEV) * 0.1).to(dtype))
+    g = torch.randn(64, 32, 3, 3, device=DEV).to(dtype)
+    q = Q.Int8WeightPerChannelFloat(w).to(DEV)
+
+    def step():
+        w.grad = None
+        y, scale, _, _ = q(w)
+        y.backward(g)
+        return y, scale, w.grad
+
+    graph, (y_s, scale_s, dw_s) = _capture(step)
+    for trial in range(2):
+        with torch.no_grad():
+            w.mul_(1.5).add_(0.01)  # new values in the captured input
+        graph.replay()
+        torch.cuda.synchronize()
+        got = (y_s.clone(), scale_s.clone(), dw_s.clone())
+        y, scale, dw = step()
+        assert torch.equal(got[0], y) and torch.equal(got[1], scale) and torch.equal(got[2], dw), trial
+
+
+def test_activation_quantizer_step_in_a_graph():
+    from bench import build_quantizer
+    torch.manual_seed(123456)
+    x = torch.randn(8, 16, 14, 14, device=DEV, dtype=torch.bfloat16).requires_grad_(True)
+    g = torch.randn_like(x)
+    qa = build_quantizer(16, True, torch.device(DEV))
+    qb = build_quantizer(16, True, torch.device(DEV))
+
+    def step_a():
+        x.grad = None
+        y = qa(x)[0]
+        y.backward(g)
+        return y, x.grad
+
+    graph, (y_s, dx_s) = _capture(step_a)
+    # bring qb's running statistics to the same state: 3 warm-up steps + the capture pass do not run kernels
+    # for the captured step, so replay once and compare against an eager twin fed the same sequence
+    for _ in range(3):
+        x.grad = None
+        qb(x)[0].backward(g)
+    with torch.no_grad():
+        x.mul_(0.5)
+    graph.replay()
+    torch.cuda.synchronize()
+    x.grad = None
+    y = qb(x)[0]
+    y.backward(g)
+    assert torch.equal(y_s, y) and torch.equal(dx_s, x.grad)
+    assert torch.equal(qa.scaling_impl.runtime_stats.running_stats, qb.scaling_impl.runtime_stats.running_stats)

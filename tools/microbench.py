@@ -90,6 +90,25 @@ def small_tensor_latency():
         wall = (time.perf_counter() - t0) / n * 1e6
         t_gpu = timeit(step, iters=20, warm=2) * 1e3
         print('%-34s wall %.0f us / step, device %.0f us / step (%d elements)' % (name, wall, t_gpu, w.numel()))
+        # the same step captured once in a HIP graph and replayed: launch-bound work without the host
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        w.grad = None
+        with torch.cuda.graph(graph):
+            y = q(w)[0]
+            y.backward(g)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            graph.replay()
+        torch.cuda.synchronize()
+        wall_g = (time.perf_counter() - t0) / n * 1e6
+        print('%-34s HIP graph replay: wall %.0f us / step' % ('', wall_g))
 
 
 if __name__ == '__main__' and 'small' in sys.argv:
