@@ -36,7 +36,8 @@ EXPORTS = (
     'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
     'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_abs_moments_workspace_bytes', 'bvq_abs_moments',
     'bvq_abs_affine_bwd', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_passes',
-    'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
+    'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd',
+    'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
 
 
 class QuantDesc(ctypes.Structure):
@@ -75,6 +76,8 @@ def _load(path=None):
         'bvq_stats_pre': (i32, [i32, i32, i32, vp, i64, i64, i64, i32, vp, vp, i64, vp]),
         'bvq_stat_bwd': (i32, [i32, i32, vp, vp, vp, vp, i64, i64, i64, i32, vp, i64, vp]),
         'bvq_fakequant_fwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp]),
+        'bvq_stats_fakequant_fwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc), vp, vp]),
+        'bvq_stats_fakequant_fwd': (i32, [ctypes.POINTER(QuantDesc), vp, dbl, i32, dbl, vp, vp, vp, vp, i64, vp]),
         'bvq_fakequant_bwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
         'bvq_absmax_scale': (i32, [i32, i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
         'bvq_running_stats_update': (i32, [i32, vp, i32, vp, i64, dbl, i32, vp]),
@@ -306,6 +309,30 @@ def fakequant_fwd(desc, x, scale, zp, want_codes=False, want_y=True):
     if not want_y:
         return codes
     return (y, codes) if want_codes else y
+
+
+def stats_fakequant_fwd(desc, x, min_val, int_threshold, scale_dtype):
+    """abs-max statistic, scale and quantize-dequantize in ONE launch (x read once) -> (stat, scale, y), or
+    None when the shape is not covered by that kernel (the caller takes the two-call route)"""
+    dev = require_device(x)
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    wsb = int(lib.bvq_stats_fakequant_fwd_workspace_bytes(ctypes.byref(desc), ptr(x), ptr(y)))
+    if wsb <= 0:
+        return None
+    channels = int(desc.channels) if (desc.scale_per_channel and desc.channels > 1) else 1
+    stat = torch.empty(channels, dtype=x.dtype, device=dev)
+    scale = torch.empty(channels, dtype=scale_dtype, device=dev)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with _DeviceGuard(dev):
+        if _timer is not None:
+            _timer.before('bvq_stats_fakequant_fwd')
+        check(lib.bvq_stats_fakequant_fwd(ctypes.byref(desc), ptr(x), float(min_val or 0.0), int(bool(min_val)),
+                                          float(int_threshold), ptr(stat), ptr(scale), ptr(y), ptr(ws), wsb,
+                                          stream_ptr(dev)), 'bvq_stats_fakequant_fwd')
+        if _timer is not None:
+            _timer.after('bvq_stats_fakequant_fwd')
+    return stat, scale, y
 
 
 def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype, pre_op=PRE_NONE):

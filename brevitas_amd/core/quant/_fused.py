@@ -196,14 +196,32 @@ class StatsFakeQuantFn(Function):
         ctx.pre_op = pre_op
         xc = x.contiguous()
         flat = xc.reshape(-1)
-        stat, scale = stats_scale(flat, int_threshold, sp, group, pre_op)
         zp = _zero_zero_point(x.device)
-        p = plan(xc, scale, zp)
-        if p is None:
-            raise nat.BvqError('StatsFakeQuantFn: unsupported operand layout (caller must pre-check)')
-        sc = scale.reshape(-1).contiguous()
-        desc = make_desc(p, xc, sc, zp.reshape(-1), qmin, qmax, round_mode, clamp_ste, nat.OUT_DEQUANT, pre_op)
-        y = nat.fakequant_fwd(desc, xc, sc, zp.reshape(-1))
+        fused = None
+        if group is None and config.FUSED_PATHS and x.dtype in _FLOATS:
+            # one launch: the channel stays in registers between the reduction and the quantization
+            # (x is read once).  Covers channels that fit a team's registers; None otherwise.
+            if len(sp.scaling_shape) > 0:
+                scale_dtype, thr_div = x.dtype, _as_dtype_value(sp.int_threshold, x.dtype)
+            else:
+                scale_dtype = torch.promote_types(x.dtype, int_threshold.dtype)
+                thr_div = sp.int_threshold
+            code = nat.dtype_code(x.dtype)
+            desc = nat.QuantDesc(sp.outer, sp.channels, sp.inner, code, code, nat.dtype_code(scale_dtype),
+                                 nat.dtype_code(zp.dtype), int(sp.channels > 1), 0, qmin, qmax, round_mode,
+                                 scalar_mode(), int(clamp_ste), nat.OUT_DEQUANT, pre_op)
+            fused = nat.stats_fakequant_fwd(desc, xc, sp.min_val, thr_div, scale_dtype)
+        if fused is not None:
+            stat, scale, y = fused
+            scale = scale.view(sp.scaling_shape)
+        else:
+            stat, scale = stats_scale(flat, int_threshold, sp, group, pre_op)
+            p = plan(xc, scale, zp)
+            if p is None:
+                raise nat.BvqError('StatsFakeQuantFn: unsupported operand layout (caller must pre-check)')
+            sc = scale.reshape(-1).contiguous()
+            desc = make_desc(p, xc, sc, zp.reshape(-1), qmin, qmax, round_mode, clamp_ste, nat.OUT_DEQUANT, pre_op)
+            y = nat.fakequant_fwd(desc, xc, sc, zp.reshape(-1))
         ctx.desc = desc
         ctx.sp = sp
         ctx.group = group

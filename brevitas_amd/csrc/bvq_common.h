@@ -154,6 +154,9 @@ __device__ __forceinline__ void store_vec(T* p, const vec_t<T, N>& v) {
 
 // bytes a call must stream before its kernels switch to the non-temporal policy
 int64_t nt_threshold_bytes();
+// host-side float -> dtype -> float rounding (python scalars that torch converts to the tensor dtype)
+float round_host(float f, int dt);
+int env_flag(const char* name, int dflt);
 
 // read element 0 / element c of a scale-like buffer of runtime dtype as float (wave-uniform use)
 __device__ __forceinline__ float load_scalar_as_f(const void* p, int dt, int64_t idx) {

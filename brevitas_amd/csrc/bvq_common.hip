@@ -5,6 +5,9 @@
 
 #include "bvq_common.h"
 
+#include <math.h>
+#include <string.h>
+
 namespace bvq {
 
 static thread_local char g_err[512] = {0};
@@ -59,6 +62,35 @@ int64_t nt_threshold_bytes() {
     return n >= 0 ? (int64_t)n : (int64_t)256 << 20;  // the Infinity Cache size
   }();
   return v;
+}
+
+// host-side float -> dtype -> float rounding (python scalars that torch converts to the tensor dtype)
+float round_host(float f, int dt) {
+  if (dt == BVQ_F32 || f != f) return f;
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if (dt == BVQ_BF16) {
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return f;
+  }
+  const float a = fabsf(f);
+  if (a == 0.f) return f;
+  if (a >= 65520.f) return copysignf(INFINITY, f);
+  int e;
+  frexpf(a, &e);
+  int qexp = e - 11;
+  if (qexp < -24) qexp = -24;
+  const float q = ldexpf(1.f, qexp);
+  return copysignf(nearbyintf(a / q) * q, f);
+}
+
+
+// integer environment knob (experiments / kill switches), read by callers once
+int env_flag(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
 
 int max_units_per_channel() {

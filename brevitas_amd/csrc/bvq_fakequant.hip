@@ -272,6 +272,186 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
 #undef BVQ_FWD_UNIT
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// statistic + quantizer in ONE kernel: the channel stays in registers between the two
+// ------------------------------------------------------------------------------------------------
+// AbsMax -> clamp_min -> / int_threshold -> IntQuant (zero zero-point): the stats-scaled graphs of
+// SURVEY 8a.  The two-kernel form reads x twice (statistic, then quantize).  Here a TEAM of
+// workgroups owns one channel at a time: every wave loads one slice of the channel (<= 8 chunks of
+// 16 bytes per lane: 8 KiB per wave) into registers, the team agrees on the channel's maximum through
+// two agent-scope atomics (max, arrival counter), and every wave quantizes what it still holds.
+// x is read ONCE: 2 instead of 3 tensor passes for the forward.
+//
+// Residency: the arrival wait needs all workgroups of a team on the chip at once.  The grid is a
+// whole number of teams and at most 2 workgroups of 512 threads per CU -- well inside what the
+// hardware admits for this kernel (MI355X_MICROARCH.md, Residency) -- and teams are consecutive block
+// ids, which are dispatched together.  As a last resort the wait is bounded: a team that does not
+// assemble within ~2 s poisons its channel with NaN and raises the error word instead of hanging.
+constexpr int kFusedSlots = 8;          // 16-byte chunks per lane held in registers
+constexpr int kFusedSliceChunks = 512;  // kWave * kFusedSlots
+constexpr int kFusedMaxWaves = 8;       // waves per workgroup
+constexpr int kFusedSpinLimit = 1 << 20;
+
+struct FusedArgs {
+  const void* x;
+  void* y;
+  void* stat_out;   // [channels], dtype of x
+  void* scale_out;  // [channels], scale_dtype
+  uint32_t* stat_bits;  // workspace, zeroed: per-channel running maximum of the |x| keys
+  uint32_t* arrive;     // workspace, zeroed: per-channel arrival counter
+  uint32_t* error;      // workspace, zeroed: set when a team did not assemble
+  int64_t outer, inner;
+  int32_t channels;
+  int32_t cpr;      // chunks per row
+  int32_t spr;      // slices per row
+  int32_t slices;   // slices per channel = outer * spr
+  int32_t team;     // workgroups per channel
+  int32_t nteams;
+  float qmin, qmax, min_val, int_threshold;
+  int32_t use_min, scale_dtype, scale_pc, scalar_cast, round_mode, pre_relu;
+};
+
+template <typename T, int RM, bool PRE, typename Div>
+__device__ __forceinline__ void fused_quantize(const vec_t<T, elem<T>::vec> (&xv)[kFusedSlots], const bool (&ok)[kFusedSlots],
+                                               T* __restrict__ yp, int lane, const Div& div, float s,
+                                               float qmin, float qmax, int mode) {
+  constexpr int VEC = elem<T>::vec;
+  constexpr bool ZP0 = sizeof(T) == 2;
+#pragma unroll
+  for (int j = 0; j < kFusedSlots; ++j) {
+    if (ok[j]) {
+      vec_t<T, VEC> yv;
+#pragma unroll
+      for (int k = 0; k < VEC; k += 2) {
+        f2 xf = widen2<T>(xv[j].v[k], xv[j].v[k + 1]);
+        if constexpr (PRE) xf = relu2(xf);
+        f2 q2;
+        const f2 r = fwd_elem2<T, RM, ZP0>(xf, div, s, 0.f, qmin, qmax, false, mode, q2);
+        pack2<T>(r, yv.v[k], yv.v[k + 1]);
+      }
+      store_vec<T, VEC, true>(yp + (int64_t)(lane + kWave * j) * VEC, yv);
+    }
+  }
+}
+
+template <typename T, int RM>
+__global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant_kernel(FusedArgs a) {
+  constexpr int VEC = elem<T>::vec;
+  __shared__ uint32_t sh_max[kFusedMaxWaves];
+  __shared__ uint32_t sh_stat;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nwaves = (int)(blockDim.x >> 6);
+  const int team = blockIdx.x / a.team;
+  const int member = blockIdx.x - team * a.team;
+  const int q = member * nwaves + wave;  // this wave's slice of every channel the team visits
+  const bool active = q < a.slices;
+  const int r = active ? q / a.spr : 0;
+  const int sl = active ? q - r * a.spr : 0;
+  const int nch = active ? (a.cpr - sl * kFusedSliceChunks < kFusedSliceChunks ? a.cpr - sl * kFusedSliceChunks
+                                                                              : kFusedSliceChunks)
+                         : 0;
+  bool ok[kFusedSlots];
+#pragma unroll
+  for (int j = 0; j < kFusedSlots; ++j) ok[j] = lane + kWave * j < nch;
+  const float qmin = rnd<T>(a.qmin), qmax = rnd<T>(a.qmax);
+
+  for (int32_t c = team; c < a.channels; c += a.nteams) {
+    const int64_t base = ((int64_t)r * a.channels + c) * a.inner + (int64_t)sl * kFusedSliceChunks * VEC;
+    const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + base;
+    T* __restrict__ yp = reinterpret_cast<T*>(a.y) + base;
+    // phase 1: the slice into registers, its maximum |x| key
+    vec_t<T, VEC> xv[kFusedSlots];
+#pragma unroll
+    for (int j = 0; j < kFusedSlots; ++j)
+      xv[j] = load_vec<T, VEC, true>(ok[j] ? xp + (int64_t)(lane + kWave * j) * VEC : reinterpret_cast<const T*>(a.x));
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < kFusedSlots; ++j) {
+      if (ok[j]) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const uint32_t b = a.pre_relu ? pre_abs_bits<T, true>(xv[j].v[k]) : pre_abs_bits<T, false>(xv[j].v[k]);
+          m = b > m ? b : m;
+        }
+      }
+    }
+    m = wave_max_u32(m);
+    if (lane == 0) sh_max[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t bm = 0;
+      for (int w = 0; w < nwaves; ++w) bm = sh_max[w] > bm ? sh_max[w] : bm;
+      // the team's agreement: max, then arrive; then wait for everybody (agent-scope atomics both sides)
+      __hip_atomic_fetch_max(&a.stat_bits[c], bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(&a.arrive[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      bool timed_out = false;
+      while (__hip_atomic_load(&a.arrive[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)a.team) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > kFusedSpinLimit) {
+          timed_out = true;
+          break;
+        }
+      }
+      uint32_t st = __hip_atomic_load(&a.stat_bits[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (timed_out) {
+        __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st = elem<T>::id == BVQ_F16 ? 0x7e00u : 0x7fc00000u;  // NaN key: the channel's outputs become NaN
+      }
+      sh_stat = st;
+    }
+    __syncthreads();
+    // statistic -> scale (ScaleEpilogue of bvq_stats.hip: same rounding points)
+    const uint32_t sb = sh_stat;
+    float stat;
+    if constexpr (elem<T>::id == BVQ_F16)
+      stat = (float)__builtin_bit_cast(f16_t, (uint16_t)sb);
+    else
+      stat = __builtin_bit_cast(float, sb);
+    const float thr = (a.use_min && stat < a.min_val) ? a.min_val : stat;
+    float s = thr / a.int_threshold;
+    // rounded to the scale's dtype as a tensor op would; a 0-dim float32 scale next to a 16-bit tensor is
+    // rounded again by the device's scalar semantics (bvq_scalar_mode)
+    if (a.scale_dtype == BVQ_BF16)
+      s = rnd<bf16_t>(s);
+    else if (a.scale_dtype == BVQ_F16)
+      s = rnd<f16_t>(s);
+    if (member == 0 && threadIdx.x == 0) {
+      if constexpr (elem<T>::id == BVQ_F32)
+        reinterpret_cast<float*>(a.stat_out)[c] = stat;
+      else
+        reinterpret_cast<T*>(a.stat_out)[c] = (T)stat;  // exact: stat is a value of T
+      if (a.scale_dtype == BVQ_F32)
+        reinterpret_cast<float*>(a.scale_out)[c] = s;
+      else if (a.scale_dtype == BVQ_BF16)
+        reinterpret_cast<bf16_t*>(a.scale_out)[c] = (bf16_t)s;
+      else
+        reinterpret_cast<f16_t*>(a.scale_out)[c] = (f16_t)s;
+    }
+    if (a.scalar_cast && !a.scale_pc) s = rnd<T>(s);
+    // phase 2: quantize what the registers still hold
+    const int mode = a.round_mode;
+    if constexpr (elem<T>::id == BVQ_BF16) {
+      if (bf16_scale_ok(s)) {
+        const DivBf16 div{1.0f / s};
+        if (a.pre_relu)
+          fused_quantize<T, RM, true>(xv, ok, yp, lane, div, s, qmin, qmax, mode);
+        else
+          fused_quantize<T, RM, false>(xv, ok, yp, lane, div, s, qmin, qmax, mode);
+        continue;
+      }
+    }
+    const DivExact div{s};
+    if (a.pre_relu)
+      fused_quantize<T, RM, true>(xv, ok, yp, lane, div, s, qmin, qmax, mode);
+    else
+      fused_quantize<T, RM, false>(xv, ok, yp, lane, div, s, qmin, qmax, mode);
+  }
+}
+
 #endif  // forward part
 
 #if BVQ_PART == 0 || BVQ_PART == 2
@@ -699,6 +879,132 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
   BVQ_DISPATCH_PAIR(d, BVQ_CALL);
 #undef BVQ_CALL
   return check_launch("bvq_fakequant_fwd");
+}
+
+
+// ---- statistic + quantizer in one launch ------------------------------------------------------------
+struct FusedPlan {
+  int vec_ok;
+  int32_t cpr, spr, slices, waves, team, nteams;
+};
+
+static int num_cus() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
+// the fused form applies when a channel fits the registers of a team that still leaves room for several
+// teams on the chip; everything else takes the two-kernel route
+static bool fused_plan(const bvq_quant_desc* d, const void* x, const void* y, FusedPlan& p) {
+  static const int enabled = env_flag("BVQ_FUSED_FWD", 1);
+  if (!enabled) return false;
+  if (d->x_dtype != d->ct_dtype || d->out_kind != BVQ_OUT_DEQUANT) return false;
+  if (d->zp_per_channel) return false;
+  const bool pc = d->scale_per_channel && d->channels > 1;
+  const int64_t outer = pc ? d->outer : 1;
+  const int64_t channels = pc ? d->channels : 1;
+  const int64_t inner = pc ? d->inner : d->outer * d->channels * d->inner;
+  const int vec = 16 / dtype_size(d->x_dtype);
+  if (inner <= 0 || outer <= 0 || inner % vec != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return false;
+  const int64_t cpr = inner / vec;
+  const int64_t spr = (cpr + kFusedSliceChunks - 1) / kFusedSliceChunks;
+  const int64_t slices = outer * spr;
+  if (cpr > (1 << 30) || slices > (1 << 20)) return false;
+  const int waves = slices < kFusedMaxWaves ? (int)slices : kFusedMaxWaves;
+  const int64_t team = (slices + waves - 1) / waves;
+  // residency budget: 2 workgroups of 512 threads per CU (or the same number of waves in smaller ones)
+  const int64_t budget = (int64_t)num_cus() * 2 * kFusedMaxWaves / waves;
+  const int64_t nteams_max = budget / team;
+  if (nteams_max < 4 && nteams_max < channels) return false;  // the channel is too large to be worth it
+  p.cpr = (int32_t)cpr;
+  p.spr = (int32_t)spr;
+  p.slices = (int32_t)slices;
+  p.waves = waves;
+  p.team = (int32_t)team;
+  p.nteams = (int32_t)(nteams_max < channels ? nteams_max : channels);
+  return true;
+}
+
+extern "C" int64_t bvq_stats_fakequant_fwd_workspace_bytes(const bvq_quant_desc* d, const void* x, const void* y) {
+  if (validate(d)) return -1;
+  FusedPlan p;
+  if (!fused_plan(d, x, y, p)) return 0;  // not applicable: use bvq_absmax_scale + bvq_fakequant_fwd
+  const int64_t channels = (d->scale_per_channel && d->channels > 1) ? d->channels : 1;
+  return (2 * channels + 4) * (int64_t)sizeof(uint32_t);
+}
+
+extern "C" int bvq_stats_fakequant_fwd(const bvq_quant_desc* d, const void* x, double min_val, int use_min,
+                                       double int_threshold, void* stat_out, void* scale_out, void* y,
+                                       void* workspace, int64_t workspace_bytes, bvq_stream_t stream) {
+  int rc = validate(d);
+  if (rc) return rc;
+  FusedPlan p;
+  if (!x || !y || !stat_out || !scale_out || !workspace) {
+    set_error("bvq_stats_fakequant_fwd: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  if (!fused_plan(d, x, y, p)) {
+    set_error("bvq_stats_fakequant_fwd: shape / layout not covered by the one-kernel form");
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  const bool pc = d->scale_per_channel && d->channels > 1;
+  const int64_t channels = pc ? d->channels : 1;
+  if (workspace_bytes < (2 * channels + 4) * (int64_t)sizeof(uint32_t)) {
+    set_error("bvq_stats_fakequant_fwd: workspace too small");
+    return BVQ_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  FusedArgs a = {};
+  a.x = x;
+  a.y = y;
+  a.stat_out = stat_out;
+  a.scale_out = scale_out;
+  a.stat_bits = reinterpret_cast<uint32_t*>(workspace);
+  a.arrive = a.stat_bits + channels;
+  a.error = a.arrive + channels;
+  a.outer = pc ? d->outer : 1;
+  a.inner = pc ? d->inner : d->outer * d->channels * d->inner;
+  a.channels = (int32_t)channels;
+  a.cpr = p.cpr;
+  a.spr = p.spr;
+  a.slices = p.slices;
+  a.team = p.team;
+  a.nteams = p.nteams;
+  a.qmin = d->qmin;
+  a.qmax = d->qmax;
+  a.min_val = round_host((float)min_val, d->x_dtype);  // python scalar -> the statistic's dtype
+  a.use_min = use_min;
+  a.int_threshold = (float)int_threshold;
+  a.scale_dtype = d->scale_dtype;
+  a.scale_pc = pc ? 1 : 0;
+  a.scalar_cast = d->scalar_mode == BVQ_SCALAR_CAST;
+  a.round_mode = d->round_mode;
+  a.pre_relu = d->pre_op == BVQ_PRE_RELU;
+  (void)hipMemsetAsync(workspace, 0, (size_t)(2 * channels + 4) * sizeof(uint32_t), st);
+  const dim3 grid((unsigned)((int64_t)p.team * p.nteams)), block((unsigned)(p.waves * kWave));
+  const bool rne = d->round_mode == BVQ_ROUND;
+#define BVQ_FUSED(T)                                                        \
+  do {                                                                      \
+    if (rne)                                                                \
+      fused_absmax_fakequant_kernel<T, BVQ_ROUND><<<grid, block, 0, st>>>(a); \
+    else                                                                    \
+      fused_absmax_fakequant_kernel<T, kAnyRM><<<grid, block, 0, st>>>(a);   \
+  } while (0)
+  if (d->x_dtype == BVQ_F32)
+    BVQ_FUSED(float);
+  else if (d->x_dtype == BVQ_BF16)
+    BVQ_FUSED(bf16_t);
+  else
+    BVQ_FUSED(f16_t);
+#undef BVQ_FUSED
+  return check_launch("bvq_stats_fakequant_fwd");
 }
 
 #endif  // forward part

@@ -615,28 +615,6 @@ using namespace bvq;
 
 static int bad_dtype(int dt) { return dt < BVQ_F32 || dt > BVQ_F16; }
 
-// host-side float -> dtype -> float rounding (python scalars that torch converts to the tensor dtype)
-static float round_host(float f, int dt) {
-  if (dt == BVQ_F32 || f != f) return f;
-  uint32_t u;
-  memcpy(&u, &f, 4);
-  if (dt == BVQ_BF16) {
-    u += 0x7fffu + ((u >> 16) & 1u);
-    u &= 0xffff0000u;
-    memcpy(&f, &u, 4);
-    return f;
-  }
-  const float a = fabsf(f);
-  if (a == 0.f) return f;
-  if (a >= 65520.f) return copysignf(INFINITY, f);
-  int e;
-  frexpf(a, &e);
-  int qexp = e - 11;
-  if (qexp < -24) qexp = -24;
-  const float q = ldexpf(1.f, qexp);
-  return copysignf(nearbyintf(a / q) * q, f);
-}
-
 extern "C" int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer, int64_t channels,
                                              int64_t inner) {
   if (bad_dtype(dtype) || outer < 0 || channels < 1 || inner < 0) return -1;

@@ -321,6 +321,20 @@ int bvq_stat_tie_apply_dscale(int pre_op, int dtype, const void* x, const void* 
 int bvq_fakequant_fwd(const bvq_quant_desc* desc, const void* x, const void* scale, const void* zp,
                       void* y, void* codes, bvq_stream_t stream);
 
+/* Statistic AND quantizer in ONE launch: AbsMax over (outer, inner) -> clamp_min(min_val) -> / int_threshold
+ * -> quantize-dequantize with that scale and a zero zero-point -- bvq_absmax_scale followed by
+ * bvq_fakequant_fwd, i.e. RescalingIntQuant.forward on the stats-scaled graphs (B/core/quant/int.py:155-163,
+ * B/core/scaling/runtime.py:50-72), reading x ONCE: a team of workgroups holds one channel in registers
+ * between the reduction and the quantization (2 tensor passes instead of 3).  Uses desc's shape, dtypes
+ * (x_dtype == ct_dtype), qmin/qmax, round_mode, scalar_mode, pre_op, scale_dtype / scale_per_channel;
+ * zero-point is +0.  stat_out: [channels] in x's dtype, scale_out: [channels] in scale_dtype.
+ * bvq_stats_fakequant_fwd_workspace_bytes returns 0 when the shape is not covered (a channel too large for
+ * the register file of a team, ragged rows, misaligned pointers): the caller then takes the two-call route. */
+int64_t bvq_stats_fakequant_fwd_workspace_bytes(const bvq_quant_desc* desc, const void* x, const void* y);
+int bvq_stats_fakequant_fwd(const bvq_quant_desc* desc, const void* x, double min_val, int use_min,
+                            double int_threshold, void* stat_out, void* scale_out, void* y, void* workspace,
+                            int64_t workspace_bytes, bvq_stream_t stream);
+
 /* bytes of scratch bvq_fakequant_bwd needs */
 int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* desc);
 
