@@ -36,7 +36,7 @@ EXPORTS = (
     'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
     'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_abs_moments_workspace_bytes', 'bvq_abs_moments',
     'bvq_abs_affine_bwd', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_passes',
-    'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd',
+    'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd', 'bvq_set_fused_max_team',
     'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
 
 
@@ -77,6 +77,7 @@ def _load(path=None):
         'bvq_stat_bwd': (i32, [i32, i32, vp, vp, vp, vp, i64, i64, i64, i32, vp, i64, vp]),
         'bvq_fakequant_fwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp]),
         'bvq_stats_fakequant_fwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc), vp, vp]),
+        'bvq_set_fused_max_team': (i32, [i32]),
         'bvq_stats_fakequant_fwd': (i32, [ctypes.POINTER(QuantDesc), vp, dbl, i32, dbl, vp, vp, vp, vp, i64, vp]),
         'bvq_fakequant_bwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
         'bvq_absmax_scale': (i32, [i32, i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
@@ -309,6 +310,11 @@ def fakequant_fwd(desc, x, scale, zp, want_codes=False, want_y=True):
     if not want_y:
         return codes
     return (y, codes) if want_codes else y
+
+
+def set_fused_max_team(workgroups):
+    """largest team of workgroups per channel the one-launch forward may use (default 1); returns the old value"""
+    return int(lib.bvq_set_fused_max_team(int(workgroups)))
 
 
 def stats_fakequant_fwd(desc, x, min_val, int_threshold, scale_dtype):

@@ -335,6 +335,11 @@ __device__ __forceinline__ void fused_quantize(const vec_t<T, elem<T>::vec> (&xv
   }
 }
 
+__global__ void fused_zero_kernel(uint32_t* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
 template <typename T, int RM>
 __global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant_kernel(FusedArgs a) {
   constexpr int VEC = elem<T>::vec;
@@ -383,6 +388,9 @@ __global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant
     if (threadIdx.x == 0) {
       uint32_t bm = 0;
       for (int w = 0; w < nwaves; ++w) bm = sh_max[w] > bm ? sh_max[w] : bm;
+      if (a.team == 1) {  // the workgroup holds the whole channel: no hand-off, no workspace
+        sh_stat = bm;
+      } else {
       // the team's agreement: max, then arrive; then wait for everybody (agent-scope atomics both sides)
       __hip_atomic_fetch_max(&a.stat_bits[c], bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -402,6 +410,7 @@ __global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant
         st = elem<T>::id == BVQ_F16 ? 0x7e00u : 0x7fc00000u;  // NaN key: the channel's outputs become NaN
       }
       sh_stat = st;
+      }
     }
     __syncthreads();
     // statistic -> scale (ScaleEpilogue of bvq_stats.hip: same rounding points)
@@ -888,6 +897,18 @@ struct FusedPlan {
   int32_t cpr, spr, slices, waves, team, nteams;
 };
 
+static int g_fused_max_team = -1;  // -1: BVQ_FUSED_MAX_TEAM or 1
+static int fused_max_team() {
+  static const int from_env = env_flag("BVQ_FUSED_MAX_TEAM", 1);
+  return g_fused_max_team >= 0 ? g_fused_max_team : from_env;
+}
+
+extern "C" int bvq_set_fused_max_team(int workgroups) {
+  const int old = fused_max_team();
+  g_fused_max_team = workgroups;
+  return old;
+}
+
 static int num_cus() {
   static int n = [] {
     int dev = 0, v = 0;
@@ -923,6 +944,11 @@ static bool fused_plan(const bvq_quant_desc* d, const void* x, const void* y, Fu
   const int64_t budget = (int64_t)num_cus() * 2 * kFusedMaxWaves / waves;
   const int64_t nteams_max = budget / team;
   if (nteams_max < 4 && nteams_max < channels) return false;  // the channel is too large to be worth it
+  // Teams of several workgroups are correct (tests/test_gpu_fused_fwd.py) but latency-bound: on the
+  // [256,512,56,56] activation (teams of 32) a round of 16 channels takes ~33 us where its 25 MB need 4 us
+  // of HBM time -- 1.05 ms against 0.40 ms for the two streaming kernels (profiles/r01_microbench_v4.txt).
+  // So by default only channels that fit ONE workgroup take this route; BVQ_FUSED_MAX_TEAM lifts the limit.
+  if (team > fused_max_team()) return false;
   p.cpr = (int32_t)cpr;
   p.spr = (int32_t)spr;
   p.slices = (int32_t)slices;
@@ -987,7 +1013,10 @@ extern "C" int bvq_stats_fakequant_fwd(const bvq_quant_desc* d, const void* x, d
   a.scalar_cast = d->scalar_mode == BVQ_SCALAR_CAST;
   a.round_mode = d->round_mode;
   a.pre_relu = d->pre_op == BVQ_PRE_RELU;
-  (void)hipMemsetAsync(workspace, 0, (size_t)(2 * channels + 4) * sizeof(uint32_t), st);
+  if (p.team > 1) {
+    const int64_t words = 2 * channels + 4;
+    fused_zero_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(a.stat_bits, words);
+  }
   const dim3 grid((unsigned)((int64_t)p.team * p.nteams)), block((unsigned)(p.waves * kWave));
   const bool rne = d->round_mode == BVQ_ROUND;
 #define BVQ_FUSED(T)                                                        \

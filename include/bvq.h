@@ -328,9 +328,13 @@ int bvq_fakequant_fwd(const bvq_quant_desc* desc, const void* x, const void* sca
  * between the reduction and the quantization (2 tensor passes instead of 3).  Uses desc's shape, dtypes
  * (x_dtype == ct_dtype), qmin/qmax, round_mode, scalar_mode, pre_op, scale_dtype / scale_per_channel;
  * zero-point is +0.  stat_out: [channels] in x's dtype, scale_out: [channels] in scale_dtype.
- * bvq_stats_fakequant_fwd_workspace_bytes returns 0 when the shape is not covered (a channel too large for
- * the register file of a team, ragged rows, misaligned pointers): the caller then takes the two-call route. */
+ * bvq_stats_fakequant_fwd_workspace_bytes returns 0 when the shape is not covered (a channel larger than the
+ * team limit below allows, ragged rows, misaligned pointers): the caller then takes the two-call route. */
 int64_t bvq_stats_fakequant_fwd_workspace_bytes(const bvq_quant_desc* desc, const void* x, const void* y);
+/* Largest team (workgroups per channel) the one-launch form may use; returns the previous value.  Default 1
+ * (or BVQ_FUSED_MAX_TEAM): a channel that fits one workgroup needs no hand-off between workgroups.  Larger
+ * teams are correct but latency-bound on MI355X; negative restores the default. */
+int bvq_set_fused_max_team(int workgroups);
 int bvq_stats_fakequant_fwd(const bvq_quant_desc* desc, const void* x, double min_val, int use_min,
                             double int_threshold, void* stat_out, void* scale_out, void* y, void* workspace,
                             int64_t workspace_bytes, bvq_stream_t stream);

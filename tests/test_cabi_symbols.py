@@ -59,3 +59,19 @@ def test_missing_library_is_an_import_error(tmp_path, monkeypatch):
     monkeypatch.setattr(_native, 'LIB_PATH', str(tmp_path / 'libbvq.so'))
     with pytest.raises(ImportError, match='no fallback'):
         _native._load()
+
+
+def test_build_script_runs_without_a_loadable_library():
+    """`python -m brevitas_amd.csrc.build` and __graft_entry__.build() must work on a fresh checkout: importing
+    the package on the way to the build script may not require the library the script is about to produce."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BREVITAS_AMD_LIB='/nonexistent/libbvq.so')  # any import of _native would fail loudly
+    r = subprocess.run([sys.executable, '-m', 'brevitas_amd.csrc.build'], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().endswith('libbvq.so')
+    r = subprocess.run([sys.executable, '-c', 'import brevitas_amd'], cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and 'There is no fallback backend' in r.stderr  # the product import still fails loudly

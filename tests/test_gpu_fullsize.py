@@ -231,8 +231,13 @@ def test_full_size_one_kernel_forward(nat, act):
     d = nat.QuantDesc(N, C, H * W, nat.BF16, nat.BF16, nat.BF16, nat.F32, 1, 0, -128.0, 127.0, 0, 0, 0, 0)
     stat, scale = nat.absmax_scale(flat, N, C, H * W, 1e-10, 128.0, torch.bfloat16)
     y = nat.fakequant_fwd(d, flat, scale, torch.zeros(1, device=DEV))
-    for _ in range(5):
-        fused = nat.stats_fakequant_fwd(d, flat, 1e-10, 128.0, torch.bfloat16)
-        assert fused is not None
-        assert torch.equal(fused[0], stat) and torch.equal(fused[1], scale)
-        assert torch.equal(bits(fused[2]), bits(y))
+    assert nat.stats_fakequant_fwd(d, flat, 1e-10, 128.0, torch.bfloat16) is None  # product default: one workgroup
+    old = nat.set_fused_max_team(64)
+    try:
+        for _ in range(5):
+            fused = nat.stats_fakequant_fwd(d, flat, 1e-10, 128.0, torch.bfloat16)
+            assert fused is not None
+            assert torch.equal(fused[0], stat) and torch.equal(fused[1], scale)
+            assert torch.equal(bits(fused[2]), bits(y))
+    finally:
+        nat.set_fused_max_team(old)

@@ -45,6 +45,10 @@ def main():
             zp = torch.zeros(1, device=dev)
             d = nat.QuantDesc(outer, ch, inner, nat.dtype_code(dt), nat.dtype_code(dt), nat.dtype_code(dt), 0,
                               int(ch > 1), 0, -128.0, 127.0, 0, 0, 0, 0)
+            if nat.stats_fakequant_fwd(d, x, 1e-10, 128.0, dt) is not None:
+                t = timeit(lambda: nat.stats_fakequant_fwd(d, x, 1e-10, 128.0, dt))
+                print('%s stat+fwd %-9s %.3f ms  %.2f TB/s (one kernel: x read once, 2 passes)' % (
+                    name, tag, t, 2 * b * n / t / 1e9))
             t = timeit(lambda: nat.fakequant_fwd(d, x, scale, zp))
             print('%s fwd    %-11s %.3f ms  %.2f TB/s' % (name, tag, t, 2 * b * n / t / 1e9))
             t = timeit(lambda: nat.fakequant_bwd(d, g, x, scale, zp, True, False))
