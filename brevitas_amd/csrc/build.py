@@ -54,7 +54,7 @@ def build(force=False, verbose=False, defines=(), out=None):
     lib_path = out or LIB
     obj_dir = OBJ_DIR if not out else os.path.join(OBJ_DIR, os.path.basename(out).replace('.', '_'))
     stamp = os.path.join(obj_dir, 'stamp')
-    dig = _digest() + ' ' + ' '.join(defines)
+    dig = (_digest() + ' ' + ' '.join(defines)).strip()
     if not force and os.path.exists(lib_path) and os.path.exists(stamp):
         with open(stamp) as fh:
             if fh.read().strip() == dig:
