@@ -92,6 +92,17 @@ __device__ __forceinline__ f2 rnd2<bf16_t>(f2 v) {
   return r;
 }
 
+// float16: one v_cvt_pk_f16_f32 for the pair.  The empty asm keeps hipcc from folding a preceding multiply
+// into v_fma_mix*_f16 with a +0 addend (which would turn a -0 product into +0; see rnd<f16_t>).
+template <>
+__device__ __forceinline__ f2 rnd2<f16_t>(f2 v) {
+  typedef f16_t f16x2 __attribute__((ext_vector_type(2)));
+  float a = v.x, b = v.y;
+  asm volatile("" : "+v"(a), "+v"(b));
+  f2 w = {a, b};
+  return __builtin_convertvector(__builtin_convertvector(w, f16x2), f2);
+}
+
 // two floats -> two T (round to nearest even), stored to a and b
 template <typename T>
 __device__ __forceinline__ void pack2(f2 v, T& a, T& b) {
@@ -102,6 +113,17 @@ template <>
 __device__ __forceinline__ void pack2<bf16_t>(f2 v, bf16_t& a, bf16_t& b) {
   typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
   const bf16x2 h = __builtin_convertvector(v, bf16x2);
+  a = h.x;
+  b = h.y;
+}
+
+template <>
+__device__ __forceinline__ void pack2<f16_t>(f2 v, f16_t& a, f16_t& b) {
+  typedef f16_t f16x2 __attribute__((ext_vector_type(2)));
+  float x = v.x, y = v.y;
+  asm volatile("" : "+v"(x), "+v"(y));
+  f2 w = {x, y};
+  const f16x2 h = __builtin_convertvector(w, f16x2);
   a = h.x;
   b = h.y;
 }

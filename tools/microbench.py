@@ -26,7 +26,7 @@ def main():
     N, C, H, W = 256, 512, 56, 56
     n = N * C * H * W
     print(torch.cuda.get_device_name(0), 'elements', n)
-    for dt, name in ((torch.bfloat16, 'bf16'), (torch.float32, 'f32')):
+    for dt, name in ((torch.bfloat16, 'bf16'), (torch.float16, 'f16'), (torch.float32, 'f32')):
         x = torch.randn(N, C, H, W, device=dev, dtype=dt).reshape(-1)
         g = torch.randn(N, C, H, W, device=dev, dtype=dt).reshape(-1)
         b = x.element_size()
