@@ -21,8 +21,8 @@ associative, so y is bit-identical); the reference itself has no cross-device re
 (nn.DataParallel replicas use local statistics).  The statistic's gradient is deposited
 where the single-device run would put it: on the first arg-max in batch order, i.e. on the lowest
 rank that holds one (per-channel), or evenly over all ties of all shards (whole tensor).  The
-scale-gradient sums are combined in rank order on every rank: bit-identical across ranks and
-run-to-run.
+scale-gradient sums are combined by the same float64 reduction of the same gathered data on every
+rank: bit-identical across ranks and run-to-run.
 """
 from typing import Optional, Tuple
 
@@ -106,11 +106,8 @@ def sync_backward(ds_local: Tensor, tie_info: Tensor, channels: int, group, firs
         allr = flat.reshape((world,) + tuple(mine.shape))
     else:
         allr = mine.unsqueeze(0)
-    # fixed (rank) order: every rank computes the same bits
-    ds_total = allr[0, 0].clone()
-    for r in range(1, world):
-        ds_total += allr[r, 0]
-    ds_total = ds_total.to(torch.float32)
+    # one float64 reduction over the rank axis of identical data on every rank: same bits everywhere
+    ds_total = allr[:, 0].sum(dim=0).to(torch.float32)
     if per_channel:
         owner = allr[:, 1].min(dim=0).values
         out = tie_info.clone()
