@@ -37,7 +37,7 @@ EXPORTS = (
     'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_abs_moments_workspace_bytes', 'bvq_abs_moments',
     'bvq_abs_affine_bwd', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_passes',
     'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd', 'bvq_set_fused_max_team',
-    'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd')
+    'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd_stats_workspace_bytes', 'bvq_fakequant_bwd_stats', 'bvq_fakequant_bwd')
 
 
 class QuantDesc(ctypes.Structure):
@@ -80,6 +80,8 @@ def _load(path=None):
         'bvq_set_fused_max_team': (i32, [i32]),
         'bvq_stats_fakequant_fwd': (i32, [ctypes.POINTER(QuantDesc), vp, dbl, i32, dbl, vp, vp, vp, vp, i64, vp]),
         'bvq_fakequant_bwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
+        'bvq_fakequant_bwd_stats_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
+        'bvq_fakequant_bwd_stats': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, i32, dbl, i32, vp, i64, vp]),
         'bvq_absmax_scale': (i32, [i32, i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
         'bvq_running_stats_update': (i32, [i32, vp, i32, vp, i64, dbl, i32, vp]),
         'bvq_abs_moments_workspace_bytes': (i64, [i32, i64, i64, i64]),
@@ -513,6 +515,29 @@ def stat_tie_apply_dscale(x, stat, dscale, scale_dtype, int_threshold, quot_dtyp
                                             ptr(info), ptr(total_ties), ptr(dx), outer, channels, inner,
                                             stream_ptr(dev)), 'bvq_stat_tie_apply_dscale')
     return dx
+
+
+def fakequant_bwd_stats(desc, g, x, scale, zp, stat, scale_dtype, int_threshold, quot_dtype, want_dscale=False):
+    """backward of the stats-scaled per-channel graph in two launches: dx with the statistic's gradient already
+    deposited on the arg-max elements (and the float32 dscale sums if asked); None if the layout is not covered"""
+    dev = require_device(g, x, scale, zp, stat)
+    wsb = int(lib.bvq_fakequant_bwd_stats_workspace_bytes(ctypes.byref(desc)))
+    if wsb <= 0:
+        return None
+    dx = torch.empty_like(x)
+    ds = torch.empty(int(desc.channels), dtype=torch.float32, device=dev)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    stat = stat.to(x.dtype).contiguous()
+    with _DeviceGuard(dev):
+        if _timer is not None:
+            _timer.before('bvq_fakequant_bwd')
+        check(lib.bvq_fakequant_bwd_stats(ctypes.byref(desc), ptr(g), ptr(x), ptr(scale), ptr(zp), ptr(stat), ptr(dx),
+                                          ptr(ds), dtype_code(scale_dtype), float(int_threshold),
+                                          dtype_code(quot_dtype), ptr(ws), wsb, stream_ptr(dev)),
+              'bvq_fakequant_bwd_stats')
+        if _timer is not None:
+            _timer.after('bvq_fakequant_bwd')
+    return (dx, ds) if want_dscale else dx
 
 
 def fakequant_bwd(desc, g, x, scale, zp, need_dscale, need_dzp, tie_stat=None):

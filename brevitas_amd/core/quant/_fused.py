@@ -240,6 +240,15 @@ class StatsFakeQuantFn(Function):
                 return None, None, None, None, None, None, None, None, None
             gy = torch.zeros(xc.shape, dtype=ct, device=xc.device)
         gy = gy.to(ct).contiguous()
+        if ctx.group is None and gscale is None and sp.channels > 1 and scale.numel() == sp.channels:
+            # per-channel scale, nothing else feeding the scale's gradient: two launches in all -- the backward
+            # kernel (dx, per-unit dscale sums and arg-max positions) and one finishing kernel that sums,
+            # converts dscale into the statistic's gradient and deposits it (None: layout not covered)
+            thr_div = _as_dtype_value(sp.int_threshold, scale.dtype)
+            dx = nat.fakequant_bwd_stats(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), stat,
+                                         scale.dtype, thr_div, scale.dtype)
+            if dx is not None:
+                return dx, None, None, None, None, None, None, None, None
         # one pass: dx, the scale-gradient sums and the positions attaining the statistic
         dx, ds, _, ties = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), True,
                                             False, tie_stat=stat)

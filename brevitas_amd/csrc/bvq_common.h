@@ -189,6 +189,16 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v |= (uint32_t)__shfl_xor((int)v, off, kWave);
   return v;
 }
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, kWave);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, kWave);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    v = o < v ? o : v;
+  }
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);

@@ -24,6 +24,7 @@ struct QuantArgs {
   float* dzp_part;  // bwd only, per-unit partial of dzp
   const void* tie_stat;          // bwd only: abs-max statistic (dtype of x) whose ties are recorded
   unsigned long long* tie_info;  // bwd only (bvq_ties.h)
+  unsigned long long* pos_part;  // bwd only: per-unit first position attaining tie_stat (instead of tie_info)
   float qmin, qmax;
   int32_t scale_dtype, zp_dtype;
   int32_t scale_pc, zp_pc;
@@ -549,6 +550,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
 
   float ds_acc = 0.f, dzp_acc = 0.f;
   uint32_t umax = 0;  // kBwdDsTies: largest |x| key this lane has seen in the unit's full chunks
+  unsigned long long tie_first = ~0ull;
   f2 ds_acc2 = splat2(0.f), dzp_acc2 = splat2(0.f);  // pairwise path; folded into the scalars at the end
   constexpr int kU = kBwdUnroll;  // chunks per lane in flight, for each of the two input streams
   ChunkCursor cur;
@@ -621,6 +623,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
     // Rare: a handful of elements per channel attain the maximum.  The hot loop only tracked this lane's
     // largest key; a lane that saw the statistic walks its chunks once more (cold code, out of the hot
     // loop's register budget) and records the positions.
+    unsigned long long first = ~0ull;  // this lane's first position attaining the statistic
     if (umax >= stat_bits) {
       ChunkCursor c2;
       c2.init(u, VEC, lane);
@@ -628,11 +631,18 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
         const vec_t<XT, VEC> xr = load_vec<XT, VEC>(xp + c2.offset(u.row_stride, VEC));
         const int64_t pos = u.pos0 + c2.pos(a.t.row_len, VEC);
         for (int k = 0; k < VEC; ++k)
-          if (pre_abs_bits<XT, PRE>(xr.v[k]) == stat_bits)
-            record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(pos + k));
+          if (pre_abs_bits<XT, PRE>(xr.v[k]) == stat_bits) {
+            if (a.pos_part) {
+              const unsigned long long p = (unsigned long long)(pos + k);
+              first = p < first ? p : first;
+            } else {
+              record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(pos + k));
+            }
+          }
         c2.next();
       }
     }
+    tie_first = first;
   }
   const int64_t i = (int64_t)cur.cpr * VEC + lane;
   if (u.nrows == 1 && i < u.len) {
@@ -642,8 +652,20 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
     if constexpr (PRE) d = xraw > 0.f ? d : 0.f;
     dxp[i] = from_f<XT>(d);
     if constexpr (MODE == kBwdDsTies) {
-      if (pre_abs_bits<XT, PRE>(xp[i]) == stat_bits)
-        record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(u.pos0 + i));
+      if (pre_abs_bits<XT, PRE>(xp[i]) == stat_bits) {
+        if (a.pos_part) {
+          const unsigned long long p = (unsigned long long)(u.pos0 + i);
+          tie_first = p < tie_first ? p : tie_first;
+        } else {
+          record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(u.pos0 + i));
+        }
+      }
+    }
+  }
+  if constexpr (MODE == kBwdDsTies) {
+    if (a.pos_part) {  // no atomics, nothing to initialise: the finishing kernel takes the minimum over units
+      tie_first = wave_min_u64(tie_first);
+      if (lane == 0) a.pos_part[u.id] = tie_first;
     }
   }
   if constexpr (MODE >= kBwdDs) {
@@ -694,6 +716,65 @@ __global__ __launch_bounds__(kBlock) void fakequant_bwd_kernel(QuantArgs a) {
   BVQ_BWD_PRE(false, div);
 #undef BVQ_BWD_PRE
 #undef BVQ_BWD_UNIT
+}
+
+
+// Finish of the stats-scaled backward in ONE launch (per-channel layouts): per channel, sum the units'
+// dscale partials (double, fixed order), take the first position attaining the statistic, turn dscale into
+// the statistic's gradient (the backward of scale = clamp_min_ste(stat) / int_threshold, same rounding
+// points as gstat_value) and deposit it on that element of dx.  Replaces tie_init + channel_sum + tie_apply.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bwd_stats_finish_kernel(const float* __restrict__ ds_part,
+                                                                  const unsigned long long* __restrict__ pos_part,
+                                                                  float* __restrict__ dscale, GstatSrc gs,
+                                                                  const void* x, void* dx, int64_t nob,
+                                                                  int32_t channels, int64_t ppr, int64_t inner) {
+  __shared__ double sh[kBlock];
+  __shared__ unsigned long long shp[kBlock];
+  const int32_t c = blockIdx.x;
+  const int64_t n = nob * ppr;
+  double acc = 0.0;
+  unsigned long long pmin = ~0ull;
+  for (int64_t k = threadIdx.x; k < n; k += kBlock) {
+    int64_t unit;
+    if (nob == 1) {
+      unit = (int64_t)c * ppr + k;
+    } else {
+      const int64_t o = k / ppr, p = k - o * ppr;
+      unit = (o * channels + c) * ppr + p;
+    }
+    acc += (double)ds_part[unit];
+    const unsigned long long q = pos_part[unit];
+    pmin = q < pmin ? q : pmin;
+  }
+  sh[threadIdx.x] = acc;
+  shp[threadIdx.x] = pmin;
+  __syncthreads();
+  for (int st = kBlock / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      sh[threadIdx.x] += sh[threadIdx.x + st];
+      const unsigned long long o = shp[threadIdx.x + st];
+      if (o < shp[threadIdx.x]) shp[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float ds = (float)sh[0];
+    dscale[c] = ds;
+    const unsigned long long pos = shp[0];
+    if (pos != ~0ull) {  // ~0: no element equals the statistic (e.g. NaN)
+      float v = round_rt(ds, gs.scale_dtype);
+      v = round_rt(v / gs.int_threshold, gs.quot_dtype);
+      const float g = rnd<T>(v);
+      const int64_t o = (int64_t)(pos / (unsigned long long)inner);
+      const int64_t i = (int64_t)(pos - (unsigned long long)o * inner);
+      const int64_t flat = (o * channels + c) * inner + i;
+      const T* xp = reinterpret_cast<const T*>(x);
+      T* dp = reinterpret_cast<T*>(dx);
+      const float term = deposit<T, BVQ_MATCH_ABS>(g, xp[flat], gs.pre_relu != 0);
+      dp[flat] = from_f<T>(to_f<T>(dp[flat]) + term);
+    }
+  }
 }
 
 #endif  // backward part
@@ -1138,4 +1219,91 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   return rc;
 }
 
+static bool bwd_stats_supported(const bvq_quant_desc* d, int64_t& units, int64_t& per_channel) {
+  if (!(d->scale_per_channel && d->channels > 1) || d->zp_per_channel) return false;
+  units = bwd_units(d);
+  per_channel = units / d->channels;
+  return per_channel <= kSumSlice;  // one finishing stage
+}
+
+extern "C" int64_t bvq_fakequant_bwd_stats_workspace_bytes(const bvq_quant_desc* d) {
+  if (validate(d)) return -1;
+  int64_t units, per_channel;
+  if (!bwd_stats_supported(d, units, per_channel)) return 0;  // use bvq_fakequant_bwd + bvq_stat_tie_apply_dscale
+  return units * (int64_t)(sizeof(float) + sizeof(unsigned long long)) + 256;
+}
+
+extern "C" int bvq_fakequant_bwd_stats(const bvq_quant_desc* d, const void* g, const void* x, const void* scale,
+                                       const void* zp, const void* stat, void* dx, float* dscale,
+                                       int scale_dtype, double int_threshold, int quot_dtype, void* workspace,
+                                       int64_t workspace_bytes, bvq_stream_t stream) {
+  int rc = validate(d);
+  if (rc) return rc;
+  int64_t units, per_channel;
+  if (!bwd_stats_supported(d, units, per_channel)) {
+    set_error("bvq_fakequant_bwd_stats: layout not covered (per-tensor scale or too many units per channel)");
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  if (scale_dtype < BVQ_F32 || scale_dtype > BVQ_F16 || quot_dtype < BVQ_F32 || quot_dtype > BVQ_F16) {
+    set_error("bvq_fakequant_bwd_stats: bad dtype");
+    return BVQ_ERR_INVALID;
+  }
+  const int64_t n = d->outer * d->channels * d->inner;
+  hipStream_t st = (hipStream_t)stream;
+  const int32_t channels = (int32_t)d->channels;
+  if (n == 0) {
+    if (dscale) (void)hipMemsetAsync(dscale, 0, sizeof(float) * channels, st);
+    return BVQ_OK;
+  }
+  if (!g || !x || !scale || !zp || !stat || !dx || !dscale || !workspace) {
+    set_error("bvq_fakequant_bwd_stats: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  const void* ptrs[3] = {x, g, dx};
+  const int els[3] = {dtype_size(d->x_dtype), dtype_size(d->ct_dtype), dtype_size(d->x_dtype)};
+  const int full = 16 / dtype_size(d->x_dtype);
+  const int vec = snap_vec(pick_vec(full, d->outer * channels, d->inner, ptrs, els, 3), full);
+  QuantArgs a = {};
+  a.t = make_tiling(d->outer, channels, d->inner, vec, 0, true);
+  const int64_t pos_off = ((a.t.units * (int64_t)sizeof(float) + 7) / 8) * 8;
+  if (workspace_bytes < pos_off + a.t.units * (int64_t)sizeof(unsigned long long)) {
+    set_error("bvq_fakequant_bwd_stats: workspace too small");
+    return BVQ_ERR_WORKSPACE;
+  }
+  a.ds_part = reinterpret_cast<float*>(workspace);
+  a.pos_part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + pos_off);
+  a.x = x;
+  a.g = g;
+  a.scale = scale;
+  a.zp = zp;
+  a.y = dx;
+  a.tie_stat = stat;
+  fill_args(a, d);
+  const bool nt =
+      n * (int64_t)(2 * dtype_size(d->x_dtype) + dtype_size(d->ct_dtype)) >= nt_threshold_bytes();
+#define BVQ_CALL(XT, CT) launch_bwd<XT, CT>(a, vec, kBwdDsTies, nt, st)
+  BVQ_DISPATCH_PAIR(d, BVQ_CALL);
+#undef BVQ_CALL
+  rc = check_launch("bvq_fakequant_bwd_stats");
+  if (rc) return rc;
+  GstatSrc gs = {};
+  gs.from_dscale = 1;
+  gs.scale_dtype = scale_dtype;
+  gs.quot_dtype = quot_dtype;
+  gs.int_threshold = (float)int_threshold;
+  gs.pre_relu = d->pre_op == BVQ_PRE_RELU;
+  const dim3 grid((unsigned)channels), block(kBlock);
+  if (d->x_dtype == BVQ_F32)
+    bwd_stats_finish_kernel<float><<<grid, block, 0, st>>>(a.ds_part, a.pos_part, dscale, gs, x, dx, a.t.nob, channels,
+                                                           a.t.ppr, d->inner);
+  else if (d->x_dtype == BVQ_BF16)
+    bwd_stats_finish_kernel<bf16_t><<<grid, block, 0, st>>>(a.ds_part, a.pos_part, dscale, gs, x, dx, a.t.nob, channels,
+                                                            a.t.ppr, d->inner);
+  else
+    bwd_stats_finish_kernel<f16_t><<<grid, block, 0, st>>>(a.ds_part, a.pos_part, dscale, gs, x, dx, a.t.nob, channels,
+                                                           a.t.ppr, d->inner);
+  return check_launch("bvq_fakequant_bwd_stats/finish");
+}
+
 #endif  // backward part
+

@@ -54,6 +54,46 @@ __device__ __forceinline__ uint32_t pre_abs_bits(T v) {
   }
 }
 
+#ifdef __HIPCC__
+// torch.sign
+__device__ __forceinline__ float sgn_f(float v) { return (float)(0.f < v) - (float)(v < 0.f); }
+
+// Where the statistic's gradient comes from: an array of the statistic's dtype, or the float32
+// scale-gradient sums of the fused quantizer backward, taken through
+//   dscale.to(scale dtype)  ->  / int_threshold (in the dtype torch computes that quotient in)  ->  .to(T)
+// i.e. the backward of  scale = clamp_min_ste(stat) / int_threshold  (B/core/quant/int.py:160).
+struct GstatSrc {
+  const void* p;
+  int32_t from_dscale;  // 0: p holds T values; 1: p holds float32 dscale sums
+  int32_t scale_dtype;
+  int32_t quot_dtype;
+  float int_threshold;
+  int32_t pre_relu;  // the statistic was taken of relu(x): the deposit's sign is sgn(relu(x))
+};
+
+__device__ __forceinline__ float round_rt(float v, int dt) {
+  return dt == BVQ_F32 ? v : (dt == BVQ_BF16 ? rnd<bf16_t>(v) : rnd<f16_t>(v));
+}
+
+template <typename T>
+__device__ __forceinline__ float gstat_value(const GstatSrc& g, int64_t c) {
+  if (!g.from_dscale) return to_f<T>(reinterpret_cast<const T*>(g.p)[c]);
+  float v = round_rt(reinterpret_cast<const float*>(g.p)[c], g.scale_dtype);
+  v = round_rt(v / g.int_threshold, g.quot_dtype);
+  return rnd<T>(v);
+}
+
+template <typename T, int MATCH>
+__device__ __forceinline__ float deposit(float g, T xv, bool pre_relu = false) {
+  if constexpr (MATCH == BVQ_MATCH_ABS) {
+    return rnd<T>(g * sgn_f(pre_relu ? relu_f(to_f<T>(xv)) : to_f<T>(xv)));
+  } else {
+    return g;
+  }
+}
+
+#endif
+
 void launch_tie_init(unsigned long long* info, int64_t channels, hipStream_t st, int first_only = 0);
 
 }  // namespace bvq

@@ -358,6 +358,20 @@ int bvq_fakequant_bwd(const bvq_quant_desc* desc, const void* g, const void* x, 
                       const void* zp, void* dx, float* dscale, float* dzp, const void* tie_stat,
                       int64_t* tie_info, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
 
+/* Backward of the stats-scaled per-channel graphs (scale = clamp_min(AbsMax(x)) / int_threshold) in
+ * TWO launches: the backward kernel (dx, per-unit dscale sums, per-unit first position attaining `stat`) and one
+ * finishing kernel per call that sums dscale (-> dscale[channels], float32), turns it into the statistic's
+ * gradient -- dscale.to(scale_dtype) / int_threshold (in quot_dtype) -> x's dtype -- and adds it, times sgn(x),
+ * to the first arg-max element of every channel in dx: bvq_fakequant_bwd(tie_stat) + bvq_stat_tie_apply_dscale
+ * without their three helper launches.  bvq_fakequant_bwd_stats_workspace_bytes returns 0 for layouts it does
+ * not cover (one scale for the whole tensor: its gradient is shared evenly by all ties; channels with more
+ * than 4096 work units): the caller then takes the two-call route. */
+int64_t bvq_fakequant_bwd_stats_workspace_bytes(const bvq_quant_desc* desc);
+int bvq_fakequant_bwd_stats(const bvq_quant_desc* desc, const void* g, const void* x, const void* scale,
+                            const void* zp, const void* stat, void* dx, float* dscale, int scale_dtype,
+                            double int_threshold, int quot_dtype, void* workspace, int64_t workspace_bytes,
+                            bvq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,3 +128,38 @@ def test_module_forward_uses_it_and_backward_is_unchanged():
     yw = qw(w)[0]
     yw.sum().backward()
     assert w.grad is not None and bool(torch.isfinite(yw).all())
+
+
+@pytest.mark.parametrize('dn', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(8, 16, 196), (64, 4, 3136), (1, 64, 4608), (37, 7, 1000), (5, 3, 49)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_two_launch_backward_equals_the_four_launch_route(dn, shape):
+    """bvq_fakequant_bwd_stats (backward kernel + one finishing kernel) against bvq_fakequant_bwd(tie_stat) +
+    bvq_stat_tie_apply_dscale (tie init, backward kernel, channel sums, deposit): dx and dscale bit for bit"""
+    from brevitas_amd import _native as nat
+    outer, ch, inner = shape
+    dt = DT[dn]
+    code = nat.dtype_code(dt)
+    torch.manual_seed(123456)
+    x = (torch.randn(outer, ch, inner, device=DEV) * 2).to(dt)
+    x[0, 1, 3] = 9.0
+    if outer > 1:
+        x[1, 1, 2] = -9.0  # a +-max tie inside a channel: the first one gets the deposit
+    x[:, 2, :] = 0.0      # an all-zero channel: every element ties, sgn(0) = 0
+    g = torch.randn(outer, ch, inner, device=DEV).to(dt)
+    flat, gf = x.reshape(-1), g.reshape(-1)
+    zp = torch.zeros(1, device=DEV)
+    for pre, clamp_ste in ((0, 0), (1, 0), (0, 1)):
+        stat, scale = nat.absmax_scale(flat, outer, ch, inner, 1e-10, 128.0, dt, pre)
+        d = nat.QuantDesc(outer, ch, inner, code, code, code, nat.F32, 1, 0, -128.0, 127.0, 0, 0, clamp_ste,
+                          nat.OUT_DEQUANT, pre)
+        res = nat.fakequant_bwd_stats(d, gf, flat, scale, zp, stat, dt, 128.0, dt, want_dscale=True)
+        assert res is not None
+        dx_a, ds_a = res
+        dx_b, ds_b, _, ties = nat.fakequant_bwd(d, gf, flat, scale, zp, True, False, tie_stat=stat)
+        nat.stat_tie_apply_dscale(flat, stat, ds_b, dt, 128.0, dt, ties, dx_b, outer, ch, inner, pre_op=pre)
+        assert torch.equal(bits(ds_a), bits(ds_b)), (pre, clamp_ste)  # as bits: a zero scale (f16) gives NaN sums
+        assert torch.equal(bits(dx_a), bits(dx_b)), (pre, clamp_ste)
+    # per-tensor scale: not covered (its gradient is shared by all ties)
+    dpt = nat.QuantDesc(1, 1, flat.numel(), code, code, code, nat.F32, 0, 0, -128.0, 127.0, 0, 0, 0, nat.OUT_DEQUANT, 0)
+    assert nat.fakequant_bwd_stats(dpt, gf, flat, scale[:1].contiguous(), zp, stat[:1].contiguous(), dt, 128.0, dt) is None
