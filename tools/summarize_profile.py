@@ -32,7 +32,7 @@ def main():
             for row in csv.DictReader(fh):
                 per[short(row['Kernel_Name'])].append((int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3)
         total = sum(sum(v) for v in per.values())
-        out.append('## rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5\n')
+        out.append('## rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 50\n')
         bj = os.path.join(root, 'kt_bench.json')
         if os.path.exists(bj):
             out.append('bench line under the profiler: `%s`\n' % open(bj).read().strip()[:600])
