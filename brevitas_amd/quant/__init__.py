@@ -13,7 +13,7 @@ import torch
 from brevitas_amd.core.bit_width import BitWidthConst
 from brevitas_amd.core.function_wrapper import (CeilSte, OverOutputChannelView, OverTensorView, RoundSte, TensorClamp,
                                                 TensorClampSte)
-from brevitas_amd.core.quant import IntQuant, RescalingIntQuant
+from brevitas_amd.core.quant import IntQuant, PrescaledRestrictIntQuant, RescalingIntQuant
 from brevitas_amd.core.restrict_val import FloatRestrictValue, PowerOfTwoRestrictValue
 from brevitas_amd.core.scaling import (IntScaling, ParameterFromRuntimeStatsScaling, ParameterScaling,
                                        PowerOfTwoIntScaling, RuntimeStatsScaling, StatsFromParameterScaling)
@@ -25,7 +25,8 @@ __all__ = ['Int8WeightPerChannelFloat', 'Int4WeightPerChannelFloat', 'Int8Weight
            'Int8ActPerTensorFloat', 'Uint8ActPerTensorFloat', 'Int8ActPerChannelFloat',
            'ShiftedUint8WeightPerTensorFloat', 'ShiftedUint8WeightPerChannelFloat', 'ShiftedUint8ActPerTensorFloat',
            'Int8WeightPerTensorFixedPoint', 'Int8WeightPerChannelFixedPoint', 'Int8ActPerTensorFixedPoint',
-           'Uint8ActPerTensorFixedPoint', 'Uint8ActPerTensorFixedPointMaxInit']
+           'Uint8ActPerTensorFixedPoint', 'Uint8ActPerTensorFixedPointMaxInit', 'Int8Bias', 'Int16Bias', 'Int24Bias',
+           'Int32Bias', 'Int8BiasPerTensorFloatInternalScaling', 'Int8BiasPerTensorFixedPointInternalScaling']
 
 SCALING_MIN_VAL = 1e-10  # B/quant/base.py:115-123, 169-182
 
@@ -222,3 +223,48 @@ def Uint8ActPerTensorFixedPointMaxInit(max_val: float, bit_width: int = 8) -> Re
         IntQuant(narrow_range=False, signed=False, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
         ParameterScaling(max_val, None, _pot(), None),
         PowerOfTwoIntScaling(signed=False), ZeroZeroPoint(), BitWidthConst(bit_width))
+
+
+# ---- bias quantizers (B/quant/scaled_int.py:64-132, fixed_point.py:79-90) ---------------------------------
+
+def _int_bias(bit_width: int) -> PrescaledRestrictIntQuant:
+    return PrescaledRestrictIntQuant(
+        IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+        BitWidthConst(bit_width))
+
+
+def Int8Bias() -> PrescaledRestrictIntQuant:
+    """IntBias with bit_width = 8 (B/quant/scaled_int.py:78-88): `q(bias, scale)` with the scale of the
+    accumulator the bias is added to, typically quant_input_scale * quant_weight_scale (one per output channel)"""
+    return _int_bias(8)
+
+
+def Int16Bias() -> PrescaledRestrictIntQuant:
+    return _int_bias(16)
+
+
+def Int24Bias() -> PrescaledRestrictIntQuant:
+    return _int_bias(24)
+
+
+def Int32Bias() -> PrescaledRestrictIntQuant:
+    return _int_bias(32)
+
+
+def Int8BiasPerTensorFloatInternalScaling(bias: torch.nn.Parameter, bit_width: int = 8) -> RescalingIntQuant:
+    """IntQuant + MaxStatsScaling + PerTensorFloatScaling8bit + BiasQuantSolver (B/quant/scaled_int.py:135-141):
+    the bias quantized with a scale of its own, from its abs-max (requires no input scale)"""
+    return RescalingIntQuant(
+        IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+        StatsFromParameterScaling(AbsMax(), OverTensorView(), 0, [bias], FloatRestrictValue(), (),
+                                  affine_rescaling=False, scaling_min_val=SCALING_MIN_VAL),
+        IntScaling(signed=True, narrow_range=False), ZeroZeroPoint(), BitWidthConst(bit_width))
+
+
+def Int8BiasPerTensorFixedPointInternalScaling(bias: torch.nn.Parameter, bit_width: int = 8) -> RescalingIntQuant:
+    """IntQuant + MaxStatsScaling + PerTensorPoTScaling8bit + BiasQuantSolver (B/quant/fixed_point.py:79-90)"""
+    return RescalingIntQuant(
+        IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+        StatsFromParameterScaling(AbsMax(), OverTensorView(), 0, [bias], _pot(), (), affine_rescaling=False,
+                                  scaling_min_val=None),
+        PowerOfTwoIntScaling(signed=True), ZeroZeroPoint(), BitWidthConst(bit_width))

@@ -105,3 +105,51 @@ def test_config5_linear_int4_weight_int8_act(oracle):
     assert torch.equal(out.view(torch.int16), F.linear(xq_o.to(DEV), wq_o.to(DEV)).view(torch.int16))
     out.float().sum().backward()
     assert torch.isfinite(layer.weight.grad.float()).all()
+
+
+@pytest.mark.parametrize('bias_bits', [8, 16, 32])
+def test_bias_quantized_with_the_accumulator_scale(bias_bits):
+    """QuantConv2d(bias_quant=IntNBias): the bias is quantized with quant_input.scale * quant_weight.scale, one
+    scale per output channel (B/nn/quant_layer.py:316-326, B/quant/scaled_int.py:64-132)"""
+    import torch.nn.functional as F
+
+    import brevitas_amd.quant as Q
+    from brevitas_amd.nn import QuantConv2d
+    torch.manual_seed(123456)
+    factory = {8: Q.Int8Bias, 16: Q.Int16Bias, 32: Q.Int32Bias}[bias_bits]
+    layer = QuantConv2d(6, 10, 3, padding=1, bias=True, weight_quant=Q.Int8WeightPerChannelFloat,
+                        input_quant=Q.Int8ActPerTensorFloat(scaling_impl_type='stats', scaling_stats_op='max'),
+                        bias_quant=factory(), device=DEV)
+    with torch.no_grad():
+        layer.bias.mul_(3.0)
+    x = torch.randn(4, 6, 9, 9, device=DEV, requires_grad=True)
+    out = layer(x)
+    xq, in_scale, _, _ = layer.input_quant(x.detach())
+    wq, w_scale, _, _ = layer.quant_weight()
+    scale = (w_scale.reshape(-1) * in_scale.reshape(-1)).reshape(-1)
+    lo, hi = -(2.0 ** (bias_bits - 1)), 2.0 ** (bias_bits - 1) - 1
+    codes = torch.clamp(torch.round(layer.bias / scale), lo, hi)
+    bq = codes * scale
+    want = F.conv2d(xq, wq, bq, padding=1)
+    assert torch.equal(out, want)
+    if bias_bits == 8:
+        assert float(codes.abs().max()) == 128.0 or float(codes.max()) == 127.0  # the 8-bit range clips a bias this large
+    out.sum().backward()
+    assert layer.bias.grad is not None and x.grad is not None and layer.weight.grad is not None
+
+
+def test_bias_quantizers_with_internal_scaling():
+    import brevitas_amd.quant as Q
+    from brevitas_amd.nn import QuantLinear
+    torch.manual_seed(123456)
+    for factory in (Q.Int8BiasPerTensorFloatInternalScaling, Q.Int8BiasPerTensorFixedPointInternalScaling):
+        layer = QuantLinear(16, 12, bias=True, weight_quant=Q.Int8WeightPerTensorFloat, bias_quant=factory, device=DEV)
+        y, scale, _, _ = layer.bias_quant(layer.bias)
+        codes = y / scale
+        assert float((codes - torch.round(codes)).abs().max()) < 1e-3 and float(codes.abs().max()) <= 128.001
+        if factory is Q.Int8BiasPerTensorFixedPointInternalScaling:
+            m, _ = torch.frexp(scale.detach())
+            assert float(m) == 0.5
+        out = layer(torch.randn(3, 16, device=DEV))
+        out.sum().backward()
+        assert layer.bias.grad is not None
