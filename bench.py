@@ -163,6 +163,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--workload', default='act_per_channel_bf16', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shard-path', action='store_true',
+                    help='developer option: run the batch-sharded code path (RCCL collectives included) even with one '
+                         'rank, to measure its fixed per-step overhead on a single GPU')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -182,10 +185,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     group = None
-    if world > 1:
+    if world > 1 or args.shard_path:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if world == 1:
+            os.environ.setdefault('MASTER_PORT', '29531')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group('nccl', device_id=device)
         group = dist.group.WORLD
 
     from brevitas_amd import _native as nat
@@ -259,7 +266,7 @@ def main():
         if baseline is not None:
             out['cpu_baseline'] = baseline
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if group is not None:
         torch.distributed.destroy_process_group()
 
 

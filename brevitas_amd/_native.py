@@ -34,7 +34,7 @@ _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 EXPORTS = (
     'bvq_abi_version', 'bvq_last_error', 'bvq_unary', 'bvq_stats_pre', 'bvq_scalar_clamp', 'bvq_tensor_clamp',
     'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
-    'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_abs_moments_workspace_bytes', 'bvq_abs_moments',
+    'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_scale_from_stat', 'bvq_shard_pack', 'bvq_shard_unpack', 'bvq_abs_moments_workspace_bytes', 'bvq_abs_moments',
     'bvq_abs_affine_bwd', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_passes',
     'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd', 'bvq_set_fused_max_team',
     'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd_stats_workspace_bytes', 'bvq_fakequant_bwd_stats', 'bvq_fakequant_bwd')
@@ -84,6 +84,9 @@ def _load(path=None):
         'bvq_fakequant_bwd_stats': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, i32, dbl, i32, vp, i64, vp]),
         'bvq_absmax_scale': (i32, [i32, i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
         'bvq_running_stats_update': (i32, [i32, vp, i32, vp, i64, dbl, i32, vp]),
+        'bvq_scale_from_stat': (i32, [vp, i64, i32, vp, dbl, i32, dbl, i32, vp, vp]),
+        'bvq_shard_pack': (i32, [vp, vp, i64, i32, i32, vp, vp]),
+        'bvq_shard_unpack': (i32, [vp, i32, i64, i32, i32, vp, vp, vp, vp]),
         'bvq_abs_moments_workspace_bytes': (i64, [i32, i64, i64, i64]),
         'bvq_abs_moments': (i32, [i32, vp, i64, i64, i64, vp, vp, i64, vp]),
         'bvq_abs_affine_bwd': (i32, [i32, vp, vp, vp, vp, i64, i64, i64, vp]),
@@ -385,6 +388,43 @@ def kth_value(x, k, outer, channels, inner, abs_key):
 
 KTH_EXPLICIT, KTH_HIGH, KTH_LOW = 0, 1, 2
 _KBINS = 2048
+
+
+def scale_from_stat(stat32, stat_dtype, min_val, int_threshold, scale_dtype):
+    """all-reduced float32 statistic [channels] -> (stat in stat_dtype, scale in scale_dtype), one launch"""
+    dev = require_device(stat32)
+    assert stat32.dtype == torch.float32 and stat32.is_contiguous()
+    n = stat32.numel()
+    stat = torch.empty(n, dtype=stat_dtype, device=dev)
+    scale = torch.empty(n, dtype=scale_dtype, device=dev)
+    with _DeviceGuard(dev):
+        check(lib.bvq_scale_from_stat(ptr(stat32), n, dtype_code(stat_dtype), ptr(stat), float(min_val or 0.0),
+                                      int(bool(min_val)), float(int_threshold), dtype_code(scale_dtype), ptr(scale),
+                                      stream_ptr(dev)), 'bvq_scale_from_stat')
+    return stat, scale
+
+
+def shard_pack(ds, tie_info, channels, rank, per_channel):
+    """this shard's float64 [2 * channels] message for the backward all-gather (include/bvq.h)"""
+    dev = require_device(ds, tie_info)
+    assert ds.dtype == torch.float32 and ds.is_contiguous() and tie_info.dtype == torch.int64
+    msg = torch.empty(2 * channels, dtype=torch.float64, device=dev)
+    with _DeviceGuard(dev):
+        check(lib.bvq_shard_pack(ptr(ds), ptr(tie_info), channels, int(rank), int(per_channel), ptr(msg),
+                                 stream_ptr(dev)), 'bvq_shard_pack')
+    return msg
+
+
+def shard_unpack(gathered, world, channels, rank, per_channel, tie_info):
+    """-> (dscale_total float32 [channels], total_ties int64 [1] or None); tie_info is updated in place"""
+    dev = require_device(gathered, tie_info)
+    assert gathered.dtype == torch.float64 and gathered.is_contiguous() and gathered.numel() == world * 2 * channels
+    ds_total = torch.empty(channels, dtype=torch.float32, device=dev)
+    total = None if per_channel else torch.empty(1, dtype=torch.int64, device=dev)
+    with _DeviceGuard(dev):
+        check(lib.bvq_shard_unpack(ptr(gathered), int(world), channels, int(rank), int(per_channel), ptr(ds_total),
+                                   ptr(tie_info), ptr(total), stream_ptr(dev)), 'bvq_shard_unpack')
+    return ds_total, total
 
 
 def abs_moments(x, outer, channels, inner):

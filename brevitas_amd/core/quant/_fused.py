@@ -172,13 +172,16 @@ def stats_scale(flat: Tensor, int_threshold: Tensor, sp, group, pre_op):
         return stat, scale.view(sp.scaling_shape)
     # batch-sharded tensor: the statistic of the whole batch is the max over the shards
     from brevitas_amd.distributed import sync_stat_max
-    stat32 = nat.stats(nat.STAT_ABSMAX, flat, sp.outer, sp.channels, sp.inner, out_f32=True, pre_op=pre_op)
-    stat = sync_stat_max(stat32, group).to(flat.dtype)
-    # _StatsScaling with float restriction: scalar_clamp_min_ste (B/core/restrict_val.py:22-42)
-    thr = nat.scalar_clamp(stat, sp.min_val, None) if sp.min_val else stat
-    # RescalingIntQuant.forward: scale = threshold / int_threshold (B/core/quant/int.py:160),
-    # on tensors shaped like the reference's so that type promotion is the same
-    return stat, thr.view(sp.scaling_shape) / int_threshold
+    stat32 = sync_stat_max(nat.stats(nat.STAT_ABSMAX, flat, sp.outer, sp.channels, sp.inner, out_f32=True,
+                                     pre_op=pre_op), group)
+    # statistic -> clamp_min -> / int_threshold with the promotion rules of the unsharded route, one launch
+    if len(sp.scaling_shape) > 0:
+        scale_dtype, thr_div = flat.dtype, _as_dtype_value(sp.int_threshold, flat.dtype)
+    else:
+        scale_dtype = torch.promote_types(flat.dtype, int_threshold.dtype)
+        thr_div = sp.int_threshold
+    stat, scale = nat.scale_from_stat(stat32, flat.dtype, sp.min_val, thr_div, scale_dtype)
+    return stat, scale.view(sp.scaling_shape)
 
 
 class StatsFakeQuantFn(Function):

@@ -315,6 +315,62 @@ __global__ __launch_bounds__(kBlock) void stat_finish_kernel(const uint32_t* __r
   }
 }
 
+// ---- batch-sharded tensors: the bookkeeping around the two collectives, one launch each ---------------
+// (brevitas_amd/distributed.py holds the same logic as torch ops for CPU tensors: the gloo protocol test)
+//
+// pack: this shard's message for the backward all-gather, float64 [2][channels]:
+//   row 0 = the shard's dscale partial sums, row 1 = its claim on each channel's deposit:
+//   per-channel / first-only layouts: `rank` if the shard holds an element attaining the statistic, else
+//   NO_OWNER; whole-tensor layouts: its number of ties.
+constexpr double kShardNoOwner = 1073741824.0;  // 2^30, above any rank
+
+__global__ void shard_pack_kernel(const float* __restrict__ ds, const long long* __restrict__ tie_info,
+                                  double* __restrict__ out, int32_t channels, int32_t rank, int per_channel) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= channels) return;
+  out[c] = (double)ds[c];
+  if (per_channel)
+    out[channels + c] = tie_info[c] >= 0 ? (double)rank : kShardNoOwner;
+  else
+    out[channels + c] = (double)tie_info[0];
+}
+
+// unpack: from the gathered [world][2][channels] messages -- the total dscale (ranks added in rank order, in
+// double: the same bits on every rank), and for per-channel layouts tie_info with every channel this shard does
+// not own disabled (the owner is the lowest rank that claimed it); for whole-tensor layouts the total tie count.
+__global__ void shard_unpack_kernel(const double* __restrict__ all, int32_t world, int32_t channels, int32_t rank,
+                                    int per_channel, float* __restrict__ ds_total, long long* __restrict__ tie_info,
+                                    long long* __restrict__ total_ties) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= channels) return;
+  double sum = 0.0, owner = kShardNoOwner, count = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double* m = all + (size_t)r * 2 * channels;
+    sum += m[c];
+    const double k = m[channels + c];
+    owner = k < owner ? k : owner;
+    count += k;
+  }
+  ds_total[c] = (float)sum;
+  if (per_channel) {
+    if (owner != (double)rank) tie_info[c] = -1;
+  } else if (c == 0) {
+    total_ties[0] = (long long)count;
+  }
+}
+
+// forward: the all-reduced float32 statistic -> statistic in x's dtype and the scale, with the rounding points of
+// clamp_min_ste(stat, min_val) / int_threshold (ScaleEpilogue above) -- one launch instead of three tiny ops
+__global__ void scale_from_stat_kernel(const float* __restrict__ stat32, void* stat_out, int stat_dtype, ScaleEpilogue ep,
+                                       int32_t channels) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= channels) return;
+  const float v = stat32[c];  // a value of stat_dtype: a max over shards of such values
+  store_stat(stat_out, stat_dtype, c, v);
+  const float thr = (ep.use_min && v < ep.min_val) ? ep.min_val : v;
+  store_stat(ep.scale_out, ep.scale_dtype, c, thr / ep.int_threshold);
+}
+
 // Running average of a statistic, as _RuntimeStats keeps it (B/core/stats/stats_wrapper.py:61-66):
 //   first batch:  running *= out
 //   afterwards :  running *= (1 - momentum) ; running += momentum * out
@@ -795,6 +851,49 @@ extern "C" int bvq_abs_affine_bwd(int dtype, const void* x, const float* a, cons
     BVQ_AFF(f16_t);
 #undef BVQ_AFF
   return check_launch("bvq_abs_affine_bwd");
+}
+
+extern "C" int bvq_shard_pack(const float* dscale, const int64_t* tie_info, int64_t channels, int rank,
+                              int per_channel, double* message, bvq_stream_t stream) {
+  if (channels < 1 || rank < 0 || !dscale || !tie_info || !message) {
+    set_error("bvq_shard_pack: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  shard_pack_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      dscale, reinterpret_cast<const long long*>(tie_info), message, (int32_t)channels, rank, per_channel);
+  return check_launch("bvq_shard_pack");
+}
+
+extern "C" int bvq_shard_unpack(const double* gathered, int world, int64_t channels, int rank, int per_channel,
+                                float* dscale_total, int64_t* tie_info, int64_t* total_ties, bvq_stream_t stream) {
+  if (channels < 1 || world < 1 || rank < 0 || rank >= world || !gathered || !dscale_total || !tie_info ||
+      (!per_channel && !total_ties)) {
+    set_error("bvq_shard_unpack: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  shard_unpack_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      gathered, world, (int32_t)channels, rank, per_channel, dscale_total, reinterpret_cast<long long*>(tie_info),
+      reinterpret_cast<long long*>(total_ties));
+  return check_launch("bvq_shard_unpack");
+}
+
+extern "C" int bvq_scale_from_stat(const float* stat32, int64_t channels, int stat_dtype, void* stat_out,
+                                   double min_val, int use_min, double int_threshold, int scale_dtype,
+                                   void* scale_out, bvq_stream_t stream) {
+  if (channels < 1 || bad_dtype(stat_dtype) || bad_dtype(scale_dtype) || !stat32 || !stat_out || !scale_out ||
+      !(int_threshold == int_threshold)) {
+    set_error("bvq_scale_from_stat: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  ScaleEpilogue ep;
+  ep.scale_out = scale_out;
+  ep.scale_dtype = scale_dtype;
+  ep.use_min = use_min;
+  ep.min_val = round_host((float)min_val, stat_dtype);
+  ep.int_threshold = (float)int_threshold;
+  scale_from_stat_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      stat32, stat_out, stat_dtype, ep, (int32_t)channels);
+  return check_launch("bvq_scale_from_stat");
 }
 
 extern "C" int bvq_running_stats_update(int run_dtype, void* running, int stat_dtype, const void* stat,

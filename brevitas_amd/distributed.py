@@ -93,6 +93,17 @@ def sync_backward(ds_local: Tensor, tie_info: Tensor, channels: int, group, firs
     """
     rank, world = world_of(group)
     per_channel = channels > 1 or first_only
+    if ds_local.is_cuda:
+        # the same protocol with the packing / unpacking in one launch each (include/bvq.h, bvq_shard_pack)
+        from brevitas_amd import _native as nat
+        mine = nat.shard_pack(ds_local.contiguous(), tie_info, channels, rank, per_channel)
+        if world > 1:
+            flat = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(flat, mine, group=group)
+        else:
+            flat = mine
+        ds_total, total = nat.shard_unpack(flat, world, channels, rank, per_channel, tie_info)
+        return ds_total, tie_info, total
     if per_channel:
         has = tie_info[:channels] >= 0
         key = torch.where(has, torch.full_like(ds_local, float(rank), dtype=torch.float64),

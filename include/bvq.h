@@ -198,6 +198,24 @@ int bvq_absmax_scale(int pre_op, int dtype, const void* x, int64_t outer, int64_
 int bvq_running_stats_update(int run_dtype, void* running, int stat_dtype, const void* stat, int64_t n,
                              double momentum, int first_batch, bvq_stream_t stream);
 
+/* ---- batch-sharded tensors (one process per GPU, the activation split along the batch) ----------------
+ * The two collectives of brevitas_amd/distributed.py carry small messages; these entry points build and consume
+ * them in one launch each instead of a dozen scale-shaped torch ops.
+ * bvq_scale_from_stat: the all-reduced (MAX) float32 statistic -> statistic in `stat_dtype` and
+ *   scale = clamp_min(stat, min_val) / int_threshold in `scale_dtype` (rounding points of bvq_absmax_scale).
+ * bvq_shard_pack: this shard's float64 [2][channels] message for the backward all-gather: its dscale sums and,
+ *   per channel, `rank` if it holds an element attaining the statistic (tie_info[c] >= 0) else 2^30
+ *   (per_channel = 0: the number of ties it holds, tie_info[0]).
+ * bvq_shard_unpack: from the gathered [world][2][channels] messages: dscale_total (double sum in rank order:
+ *   the same bits on every rank) and, per_channel, tie_info[c] = -1 for every channel whose lowest claiming rank
+ *   is another shard; per_channel = 0: total_ties[0] = ties over all shards. */
+int bvq_scale_from_stat(const float* stat32, int64_t channels, int stat_dtype, void* stat_out, double min_val,
+                        int use_min, double int_threshold, int scale_dtype, void* scale_out, bvq_stream_t stream);
+int bvq_shard_pack(const float* dscale, const int64_t* tie_info, int64_t channels, int rank, int per_channel,
+                   double* message, bvq_stream_t stream);
+int bvq_shard_unpack(const double* gathered, int world, int64_t channels, int rank, int per_channel,
+                     float* dscale_total, int64_t* tie_info, int64_t* total_ties, bvq_stream_t stream);
+
 /* ---- moment statistics ---------------------------------------------------------------------------
  * sums[c] = SUM |x|, sums[channels + c] = SUM x^2 over the `outer` and `inner` axes, as float32 (per-unit
  * float32 partials, double accumulation across units, fixed order): what AbsAve (mean |x|) and

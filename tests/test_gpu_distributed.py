@@ -126,3 +126,55 @@ def test_sharded_named_act_quantizers_equal_unsharded(nccl_world1, name, dtype):
         if diff.numel():
             a, b = dx0.reshape(-1)[diff].float(), dx1.reshape(-1)[diff].float()
             assert bool(((a - b).abs() <= 2.0 ** -6 * (a.abs() + b.abs() + 1e-3)).all())
+
+
+@pytest.mark.parametrize('per_channel', [True, False], ids=['per_channel', 'per_tensor'])
+def test_shard_pack_unpack_kernels_for_three_ranks(per_channel):
+    """bvq_shard_pack / bvq_shard_unpack with the messages of three simulated ranks (no collective needed) against
+    the torch-op statement of the same protocol (the one the gloo test runs on CPU tensors)"""
+    from brevitas_amd import _native as nat
+    torch.manual_seed(123456)
+    world, C = 3, 37 if per_channel else 1
+    ds = [torch.randn(C, device=DEV) * 10 for _ in range(world)]
+    if per_channel:
+        infos = [torch.randint(-1, 50, (C,), device=DEV, dtype=torch.int64).clamp_min(-1) for _ in range(world)]
+        infos[0][:5] = -1   # channels nobody on rank 0 holds
+        infos[1][:3] = -1
+        infos[2][:2] = -1   # channels 0,1: nobody at all
+    else:
+        infos = [torch.tensor([k, 0, 11, 12], device=DEV, dtype=torch.int64) for k in (2, 0, 5)]
+    msgs = [nat.shard_pack(ds[r], infos[r], C, r, per_channel) for r in range(world)]
+    gathered = torch.cat(msgs)
+    all_ = gathered.view(world, 2, C)
+    want_ds = all_[:, 0].sum(dim=0).to(torch.float32)
+    for r in range(world):
+        info = infos[r].clone()
+        ds_total, total = nat.shard_unpack(gathered, world, C, r, per_channel, info)
+        assert torch.allclose(ds_total, want_ds, rtol=1e-6, atol=1e-6)
+        if per_channel:
+            owner = all_[:, 1].min(dim=0).values
+            want = torch.where(owner == float(r), infos[r][:C], torch.full_like(infos[r][:C], -1))
+            assert torch.equal(info[:C], want) and total is None
+        else:
+            assert int(total) == 7 and torch.equal(info, infos[r])
+    # every rank computes the same bits
+    outs = [nat.shard_unpack(gathered, world, C, r, per_channel, infos[r].clone())[0] for r in range(world)]
+    assert all(torch.equal(outs[0].view(torch.int32), o.view(torch.int32)) for o in outs)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16], ids=['bf16', 'f32', 'f16'])
+def test_scale_from_stat_equals_the_three_torch_ops(dtype):
+    from brevitas_amd import _native as nat
+    torch.manual_seed(1)
+    stat32 = (torch.rand(64, device=DEV) * 5).to(dtype).float()  # values of dtype, as a max of such values is
+    stat32[3] = 0.0
+    stat32[4] = float('nan')
+    stat, scale = nat.scale_from_stat(stat32, dtype, 1e-10, 128.0, dtype)
+    want_stat = stat32.to(dtype)
+    want_scale = torch.clamp_min(want_stat, 1e-10) / torch.tensor(128.0, device=DEV)
+    view = torch.int16 if dtype != torch.float32 else torch.int32
+    assert torch.equal(stat.view(view), want_stat.view(view))
+    assert torch.equal(scale.view(view), want_scale.to(dtype).view(view))
+    # 0-dim promotion: float32 scale of a 16-bit statistic
+    stat, scale = nat.scale_from_stat(stat32[:1].contiguous(), dtype, None, 127.0, torch.float32)
+    assert scale.dtype == torch.float32 and float(scale) == float(stat32[0].to(dtype).float() / 127.0)
