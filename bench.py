@@ -168,6 +168,12 @@ def main():
                          'rank, to measure its fixed per-step overhead on a single GPU')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: everything else this process or its libraries print
+    # (RCCL's version banner goes to stdout) is sent to stderr until then
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -265,7 +271,8 @@ def main():
         }
         if baseline is not None:
             out['cpu_baseline'] = baseline
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + '\n').encode())
     if group is not None:
         torch.distributed.destroy_process_group()
 
