@@ -36,6 +36,14 @@ def main():
         print('%s copy           %.3f ms  %.2f TB/s' % (name, t, 2 * b * n / t / 1e9))
         t = timeit(lambda: nat.unary(nat.OP_ABS, x))
         print('%s |x| map kernel  %.3f ms  %.2f TB/s (grid-stride, default cache policy)' % (name, t, 2 * b * n / t / 1e9))
+        k = int(0.99999 * n + 0.5)
+        t = timeit(lambda: nat.kth_value(x, k, 1, 1, n, True))
+        passes = 3 if dt == torch.float32 else 2
+        print('%s percentile(99.999) of |x| per-tensor %.3f ms  %.2f TB/s (%d passes; torch.kthvalue: see below)' % (
+            name, t, passes * b * n / t / 1e9, passes))
+        if dt == torch.bfloat16:
+            t0 = timeit(lambda: x.abs().kthvalue(k), iters=2, warm=1)
+            print('%s torch: x.abs().kthvalue(k)          %.3f ms' % (name, t0))
         for tag, ch in (('per-tensor', 1), ('per-channel', C)):
             outer, inner = (N, H * W) if ch > 1 else (1, n)
             t = timeit(lambda: nat.stats(nat.STAT_ABSMAX, x, outer, ch, inner))
