@@ -122,20 +122,6 @@ __device__ __forceinline__ vec_t<T, N> load_vec(const T* p) {
 }
 template <typename T, int N, bool NT = false>
 __device__ __forceinline__ void store_vec(T* p, const vec_t<T, N>& v) {
-#ifdef BVQ_STORE_ASM  // build-time experiment: explicit cache-policy bits on the streaming store
-  if constexpr (NT && sizeof(T) * N == 16) {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 d = __builtin_bit_cast(u32x4, v);
-#if BVQ_STORE_ASM == 1
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
-#elif BVQ_STORE_ASM == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
-#else
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(d) : "memory");
-#endif
-    return;
-  }
-#endif
   if constexpr (NT && sizeof(T) * N == 16) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
@@ -224,7 +210,6 @@ struct Tiling {
   int64_t units;      // nob * channels * ppr
   int32_t channels;
   int32_t rpu;        // rows (outer indices) per unit
-  int32_t reverse;    // units are visited from the end of the tensor to its start
 };
 
 // elements one wave handles per piece, in 16-byte chunks per lane.  8 chunks = 8 KiB (2-byte types).
@@ -262,7 +247,6 @@ __device__ __forceinline__ Unit locate_unit(const Tiling& t) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   u.id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   u.valid = u.id < t.units;
-  if (t.reverse) u.id = t.units - 1 - u.id;  // walk the tensor back to front (see make_tiling)
   if (!u.valid) {
     u.base = u.row_stride = u.len = u.pos0 = 0;
     u.nrows = u.channel = 0;
