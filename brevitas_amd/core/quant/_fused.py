@@ -91,18 +91,49 @@ def _reduce_like(sums: Tensor, like: Tensor) -> Tensor:
     return sums.reshape(like.shape).to(like.dtype)
 
 
+def _memory_order(x: Tensor, channels: int):
+    """-> (contiguous tensor holding x's elements, permutation that maps a same-ordered result back to x's
+    logical layout or None).  A per-tensor quantizer does not care about element order, so a dense
+    channels_last tensor (the layout MIOpen prefers) is taken as it lies in memory instead of being copied to
+    NCHW and back; every other case is `x.contiguous()` like the reference's own reshape."""
+    if x.is_contiguous() or channels != 1:
+        return x.contiguous(), None
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+        return x.permute(0, 2, 3, 1), (0, 3, 1, 2)
+    if x.dim() == 5 and x.is_contiguous(memory_format=torch.channels_last_3d):
+        return x.permute(0, 2, 3, 4, 1), (0, 4, 1, 2, 3)
+    return x.contiguous(), None
+
+
+def _like_memory_order(t: Tensor, back) -> Tensor:
+    """bring an incoming gradient into the element order the forward used"""
+    if back is None:
+        return t.contiguous()
+    inv = [0] * len(back)
+    for i, b in enumerate(back):
+        inv[b] = i
+    return t.permute(inv).contiguous()
+
+
+def _restore(t: Tensor, back) -> Tensor:
+    return t if back is None else t.permute(back)
+
+
 class FakeQuantFn(Function):
     """IntQuant.forward / IntQuant.to_int on the fused kernel (B/core/quant/int_base.py:63-97)"""
 
     @staticmethod
     def forward(ctx, x, scale, zp, p, qmin, qmax, round_mode, clamp_ste, out_kind, pre_op=nat.PRE_NONE):
-        xc = x.contiguous()
+        xc, back = _memory_order(x, p.channels)
         sc = scale.reshape(-1).contiguous()
         zc = zp.reshape(-1).contiguous()
         desc = make_desc(p, xc, sc, zc, qmin, qmax, round_mode, clamp_ste, out_kind, pre_op)
         y = nat.fakequant_fwd(desc, xc, sc, zc)
         ctx.desc = desc
+        ctx.back = back
         ctx.save_for_backward(xc, scale, zp)
+        if back is not None:
+            y = y.permute(back)
         if out_kind == nat.OUT_INT:
             ctx.mark_non_differentiable(y)
         return y
@@ -113,9 +144,11 @@ class FakeQuantFn(Function):
         desc = ctx.desc
         need_ds, need_dz = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
-        gy = gy.to(ct).contiguous()
+        gy = _like_memory_order(gy.to(ct), ctx.back)
         dx, ds, dz = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1).contiguous(),
                                        need_ds, need_dz)
+        if ctx.back is not None:
+            dx = dx.permute(ctx.back)
         ds = _reduce_like(ds, scale) if need_ds else None
         dz = _reduce_like(dz, zp) if need_dz else None
         return dx, ds, dz, None, None, None, None, None, None, None
@@ -197,7 +230,8 @@ class StatsFakeQuantFn(Function):
     def forward(ctx, x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, group=None, pre_op=nat.PRE_NONE):
         ctx.set_materialize_grads(False)  # an unused `scale` output must not cost a zero-fill + add
         ctx.pre_op = pre_op
-        xc = x.contiguous()
+        xc, back = _memory_order(x, sp.channels)
+        ctx.back = back
         flat = xc.reshape(-1)
         zp = _zero_zero_point(x.device)
         fused = None
@@ -231,6 +265,8 @@ class StatsFakeQuantFn(Function):
         ctx.save_for_backward(xc, scale, zp, stat, int_threshold)
         stat_out = stat.view(sp.scaling_shape)
         ctx.mark_non_differentiable(stat_out)
+        if back is not None:
+            y = y.permute(back)
         return y, scale, stat_out
 
     @staticmethod
@@ -242,7 +278,8 @@ class StatsFakeQuantFn(Function):
             if gscale is None:
                 return None, None, None, None, None, None, None, None, None
             gy = torch.zeros(xc.shape, dtype=ct, device=xc.device)
-        gy = gy.to(ct).contiguous()
+        else:
+            gy = _like_memory_order(gy.to(ct), ctx.back)
         if ctx.group is None and gscale is None and sp.channels > 1 and scale.numel() == sp.channels:
             # per-channel scale, nothing else feeding the scale's gradient: two launches in all -- the backward
             # kernel (dx, per-unit dscale sums and arg-max positions) and one finishing kernel that sums,
@@ -251,7 +288,7 @@ class StatsFakeQuantFn(Function):
             dx = nat.fakequant_bwd_stats(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), stat,
                                          scale.dtype, thr_div, scale.dtype)
             if dx is not None:
-                return dx, None, None, None, None, None, None, None, None
+                return _restore(dx, ctx.back), None, None, None, None, None, None, None, None
         # one pass: dx, the scale-gradient sums and the positions attaining the statistic
         dx, ds, _, ties = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), True,
                                             False, tie_stat=stat)
@@ -263,7 +300,7 @@ class StatsFakeQuantFn(Function):
             thr_div = _as_dtype_value(sp.int_threshold, scale.dtype) if dimensioned else sp.int_threshold
             nat.stat_tie_apply_dscale(xc.reshape(-1), stat, ds, scale.dtype, thr_div, quot_dtype, ties,
                                       dx.reshape(-1), sp.outer, sp.channels, sp.inner, pre_op=ctx.pre_op)
-            return dx, None, None, None, None, None, None, None, None
+            return _restore(dx, ctx.back), None, None, None, None, None, None, None, None
         if ctx.group is not None:
             # sum the shards' partial sums, and agree on which shard deposits the statistic's gradient
             from brevitas_amd.distributed import sync_backward
@@ -278,4 +315,4 @@ class StatsFakeQuantFn(Function):
         dstat = (ds / int_threshold).to(stat.dtype).reshape(-1).contiguous()
         nat.stat_tie_apply(nat.MATCH_ABS, xc.reshape(-1), stat, dstat, ties, dx.reshape(-1), sp.outer,
                            sp.channels, sp.inner, mode_add=True, total_ties=total_ties, pre_op=ctx.pre_op)
-        return dx, None, None, None, None, None, None, None, None
+        return _restore(dx, ctx.back), None, None, None, None, None, None, None, None

@@ -346,3 +346,33 @@ def test_int_codes_emission(c):
     assert codes2.dtype == codes.dtype
     if not (c.arr('scale').size == 1 and c['dtypes']['scale'] == 'f32' and c['dtypes']['x'] != 'f32'):
         assert np.array_equal(codes2.cpu().numpy()[fin], codes.cpu().numpy()[fin])
+
+
+@pytest.mark.parametrize('kind', ['learned_scale', 'stats_scaled'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_channels_last_activation_is_quantized_in_memory_order(kind, dtype):
+    """a per-tensor quantizer takes a dense channels_last tensor as it lies in memory (no NCHW copy) and hands
+    back channels_last results: same values and gradients as for the contiguous tensor"""
+    import brevitas_amd.quant as Q
+    torch.manual_seed(123456)
+    x = torch.randn(4, 6, 5, 7, device=DEV).to(dtype)
+    g = torch.randn(4, 6, 5, 7, device=DEV).to(dtype)
+    outs = []
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        if kind == 'learned_scale':
+            q = Q.Int8ActPerTensorFloat(scaling_impl_type='parameter', scaling_init=2.0).to(DEV).to(dtype)
+        else:
+            q = Q.Int8ActPerTensorFloat(scaling_impl_type='stats', scaling_stats_op='max').to(DEV)
+        xi = x.clone().to(memory_format=fmt).requires_grad_(True)
+        y, scale, _, _ = q(xi)
+        y.backward(g.to(memory_format=fmt))
+        outs.append((y.detach(), scale.detach(), xi.grad))
+        if fmt is torch.channels_last:
+            assert y.is_contiguous(memory_format=torch.channels_last)
+            assert xi.grad.is_contiguous(memory_format=torch.channels_last)
+    (y0, s0, dx0), (y1, s1, dx1) = outs
+    assert torch.equal(y0, y1) and torch.equal(s0, s1)
+    if kind == 'learned_scale':
+        assert torch.equal(dx0, dx1)
+    else:  # the arg-max deposit: same element, same value
+        assert int((dx0 != dx1).sum()) == 0
