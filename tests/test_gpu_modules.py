@@ -374,5 +374,9 @@ def test_channels_last_activation_is_quantized_in_memory_order(kind, dtype):
     assert torch.equal(y0, y1) and torch.equal(s0, s1)
     if kind == 'learned_scale':
         assert torch.equal(dx0, dx1)
-    else:  # the arg-max deposit: same element, same value
-        assert int((dx0 != dx1).sum()) == 0
+    else:  # the arg-max element also carries the reduced scale gradient, summed in a different element order
+        diff = (dx0 != dx1).reshape(-1).nonzero().reshape(-1)
+        assert diff.numel() <= 1
+        if diff.numel():
+            a, b = dx0.reshape(-1)[diff].float(), dx1.reshape(-1)[diff].float()
+            assert bool(((a - b).abs() <= 2.0 ** -6 * (a.abs() + b.abs() + 1e-3)).all())
