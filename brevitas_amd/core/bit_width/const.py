@@ -25,18 +25,20 @@ class BitWidthConst(torch.nn.Module):
 
 
 class MsbClampBitWidth(torch.nn.Module):
-    """output bit width = clamp(|input_bit_width - bits_to_remove|, min, max) (B/core/bit_width/const.py:43-66):
-    the accumulator-side bit width of clamp / truncation quantizers"""
+    """Bit width of an accumulator after dropping most-significant bits (drop-in for
+    B/core/bit_width/const.py:43-66): |input_bit_width - bits_to_remove|, kept inside
+    [min_overall_bit_width, max_overall_bit_width] by a straight-through clamp, so that a learned
+    `bits_to_remove` (RemoveBitwidthParameter) keeps receiving a gradient at the bounds."""
 
     def __init__(self, bit_width_to_remove_impl: torch.nn.Module, min_overall_bit_width: int,
                  max_overall_bit_width: int) -> None:
         super().__init__()
+        self.bit_width_to_remove_impl = bit_width_to_remove_impl
         self.min_overall_bit_width = BitWidthConst(min_overall_bit_width)
         self.max_overall_bit_width = BitWidthConst(max_overall_bit_width)
-        self.bit_width_to_remove_impl = bit_width_to_remove_impl
 
     def forward(self, input_bit_width: Tensor) -> Tensor:
         from brevitas_amd.function.ops_ste import tensor_clamp_ste
-        bit_width_to_remove = self.bit_width_to_remove_impl()
-        output_bit_width = torch.abs(input_bit_width - bit_width_to_remove)
-        return tensor_clamp_ste(output_bit_width, self.min_overall_bit_width(), self.max_overall_bit_width())
+        kept = torch.abs(input_bit_width - self.bit_width_to_remove_impl())
+        lo, hi = self.min_overall_bit_width(), self.max_overall_bit_width()
+        return tensor_clamp_ste(kept, lo, hi)

@@ -30,8 +30,7 @@ class TernaryQuant(torch.nn.Module):
 
     def forward(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
         scale = self.scaling_impl(x)
-        mask = x.abs().gt(self.threshold * scale)
-        y = mask.float() * ternary_sign_ste(x)
-        y = y * scale
-        y = self.delay_wrapper(x, y)
+        # {-1, 0, +1}: zero inside the dead zone |x| <= threshold * scale, the sign outside (gradient passes through)
+        outside = torch.abs(x) > self.threshold * scale
+        y = self.delay_wrapper(x, outside.float() * ternary_sign_ste(x) * scale)
         return y, scale, self.zero_point(), self.bit_width()

@@ -4,14 +4,17 @@ from typing import List, Optional, Tuple
 import torch
 from torch.nn import Module, Parameter
 
-import brevitas_amd.config as config
+from brevitas_amd.core._state import TolerantLoad
 from brevitas_amd.core.function_wrapper import Identity
 from brevitas_amd.core.restrict_val import _RestrictClampValue
 from brevitas_amd.core.stats import DEFAULT_MOMENTUM, _ParameterListStats, _RuntimeStats
 from brevitas_amd.function.ops_ste import abs_binary_sign_grad
 
 
-class _AffineRescaling(torch.nn.Module):
+class _AffineRescaling(TolerantLoad, torch.nn.Module):
+    """learned affine map of the statistic, kept positive: |stat * affine_weight + affine_bias|"""
+
+    bvq_float_checkpoint_ok = ('affine_weight', 'affine_bias')
 
     def __init__(self, scaling_shape):
         super().__init__()
@@ -19,16 +22,7 @@ class _AffineRescaling(torch.nn.Module):
         self.affine_bias = Parameter(torch.zeros(scaling_shape))
 
     def forward(self, x):
-        out = x * self.affine_weight + self.affine_bias
-        return abs_binary_sign_grad(out)
-
-    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
-                              error_msgs):
-        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
-                                      error_msgs)
-        for key in (prefix + 'affine_weight', prefix + 'affine_bias'):
-            if config.IGNORE_MISSING_KEYS and key in missing_keys:
-                missing_keys.remove(key)
+        return abs_binary_sign_grad(x * self.affine_weight + self.affine_bias)
 
 
 class _StatsScaling(torch.nn.Module):

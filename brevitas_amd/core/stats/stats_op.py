@@ -13,6 +13,7 @@ from torch import Tensor
 from torch.autograd import Function
 
 from brevitas_amd import _native as nat
+from brevitas_amd.core._state import TolerantLoad
 
 
 def _as_rows(x: Tensor, dim: Optional[int]):
@@ -381,11 +382,12 @@ class MeanSigmaStd(torch.nn.Module):
         return self.impl(x, self.sigma())
 
 
-class MeanLearnedSigmaStd(torch.nn.Module):
+class MeanLearnedSigmaStd(TolerantLoad, torch.nn.Module):
     """MeanSigmaStd with a learned sigma (B/core/stats/stats_op.py:243-279).  The reference snapshot
     registers the parameter as `value` but reads `self.sigma` in forward and in its state-dict hook; the
     name used consistently here is `sigma` (with the reference's `learned_sigma` retro-compatibility key)."""
     bvq_is_stat = True
+    bvq_float_checkpoint_ok = ('sigma',)
 
     def __init__(self, sigma: float, stats_output_shape, stats_reduce_dim: Optional[int] = None,
                  std_dev_epsilon: float = DEFAULT_STD_DEV_EPSILON) -> None:
@@ -399,14 +401,8 @@ class MeanLearnedSigmaStd(torch.nn.Module):
     def forward(self, x: Tensor):
         return self.impl(x, self.sigma.view(self.sigma.shape))
 
-    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
-                              error_msgs):
-        import brevitas_amd.config as config
-        value_key = prefix + 'sigma'
-        retrocomp_value_key = prefix + 'learned_sigma'
-        if retrocomp_value_key in state_dict:
-            state_dict[value_key] = state_dict.pop(retrocomp_value_key)
-        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
-                                      error_msgs)
-        if config.IGNORE_MISSING_KEYS and value_key in missing_keys:
-            missing_keys.remove(value_key)
+    def _load_from_state_dict(self, state_dict, prefix, *hook_args):
+        legacy = prefix + 'learned_sigma'
+        if legacy in state_dict:
+            state_dict[prefix + 'sigma'] = state_dict.pop(legacy)
+        super()._load_from_state_dict(state_dict, prefix, *hook_args)

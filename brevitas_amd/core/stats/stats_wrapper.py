@@ -6,7 +6,7 @@ from typing import List, Tuple
 import torch
 from torch import Tensor, nn
 
-import brevitas_amd.config as config
+from brevitas_amd.core._state import TolerantLoad
 
 from .view_wrapper import _ViewCatParameterWrapper, _ViewParameterWrapper
 
@@ -26,8 +26,10 @@ class _Stats(torch.nn.Module):
         return stats.view(self.stats_output_shape)
 
 
-class _RuntimeStats(torch.nn.Module):
+class _RuntimeStats(TolerantLoad, torch.nn.Module):
     """training: statistic of the current batch, folded into `running_stats`; eval: the buffer"""
+
+    bvq_float_checkpoint_ok = ('running_stats',)
 
     def __init__(self, stats_impl: nn.Module, stats_output_shape: Tuple[int, ...],
                  stats_input_view_shape_impl: nn.Module, stats_buffer_momentum: float = DEFAULT_MOMENTUM) -> None:
@@ -56,24 +58,11 @@ class _RuntimeStats(torch.nn.Module):
             self.running_stats += self.momentum * out
 
     def forward(self, stats_input) -> Tensor:
-        if self.training:
-            stats_input = self.stats_input_view_shape_impl(stats_input)
-            out = self.stats(stats_input)
-            self.update_running_stats(out)
-        else:
-            out = self.running_stats
-        return out
-
-    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
-                              error_msgs):
-        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
-                                      error_msgs)
-        running_stats_key = prefix + 'running_stats'
-        if config.IGNORE_MISSING_KEYS and running_stats_key in missing_keys:
-            missing_keys.remove(running_stats_key)
-        training_key = prefix + 'training'
-        if training_key in missing_keys:
-            missing_keys.remove(training_key)
+        if not self.training:
+            return self.running_stats
+        batch_stat = self.stats(self.stats_input_view_shape_impl(stats_input))
+        self.update_running_stats(batch_stat)
+        return batch_stat
 
 
 class _ParameterListStats(torch.nn.Module):
@@ -83,19 +72,17 @@ class _ParameterListStats(torch.nn.Module):
                  stats_input_view_shape_impl: nn.Module, stats_input_concat_dim: int,
                  tracked_parameter_list: List[torch.nn.Parameter]) -> None:
         super().__init__()
+        head, others = tracked_parameter_list[0], tracked_parameter_list[1:]
         self.stats_input_concat_dim = stats_input_concat_dim
-        self.first_tracked_param = _ViewParameterWrapper(tracked_parameter_list[0], stats_input_view_shape_impl)
-        if len(tracked_parameter_list) > 1:
-            self.extra_tracked_params_list = torch.nn.ModuleList([
-                _ViewCatParameterWrapper(param, stats_input_view_shape_impl, stats_input_concat_dim)
-                for param in tracked_parameter_list[1:]])
-        else:
-            self.extra_tracked_params_list = None
+        self.first_tracked_param = _ViewParameterWrapper(head, stats_input_view_shape_impl)
+        # None (not an empty list) when a single parameter is tracked: the fused weight path keys on it
+        self.extra_tracked_params_list = torch.nn.ModuleList(
+            _ViewCatParameterWrapper(w, stats_input_view_shape_impl, stats_input_concat_dim) for w in others
+        ) if others else None
         self.stats = _Stats(stats_impl, stats_output_shape)
 
     def forward(self) -> torch.Tensor:
-        stats_input = self.first_tracked_param()
-        if self.extra_tracked_params_list is not None:
-            for extra_tracked_param in self.extra_tracked_params_list:
-                stats_input = extra_tracked_param(stats_input)
-        return self.stats(stats_input)
+        viewed = self.first_tracked_param()
+        for appended in (self.extra_tracked_params_list or ()):
+            viewed = appended(viewed)  # concatenates its own parameter's view to what came before
+        return self.stats(viewed)

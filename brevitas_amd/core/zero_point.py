@@ -12,9 +12,9 @@ import torch
 from torch import Tensor
 from torch.nn import Module, Parameter
 
-import brevitas_amd.config as config
+from brevitas_amd.core._state import CollectThenLearn, TolerantLoad
 from brevitas_amd.core.stats import DEFAULT_MOMENTUM, SCALAR_SHAPE, _ParameterListStats
-from brevitas_amd.core.utils import StatelessBuffer, inplace_momentum_update, inplace_tensor_add
+from brevitas_amd.core.utils import StatelessBuffer, inplace_tensor_add
 from brevitas_amd.function.ops_ste import abs_binary_sign_grad
 
 __all__ = ['ZeroZeroPoint', 'StatsFromParameterZeroPoint', 'ParameterFromRuntimeZeroPoint', 'ParameterZeroPoint']
@@ -64,100 +64,54 @@ class StatsFromParameterZeroPoint(torch.nn.Module):
         return self.scale_shift_zero_point(-stats, scale, bit_width)
 
 
-class ParameterFromRuntimeZeroPoint(torch.nn.Module):
-    """collect a statistic of the activation for `collect_stats_steps` training steps, then learn the
-    zero-point as a parameter (:86-183)"""
+class ParameterFromRuntimeZeroPoint(CollectThenLearn, torch.nn.Module):
+    """a statistic of the activation (e.g. its low percentile) averaged over `collect_stats_steps` training steps,
+    then learned as the parameter `value` (B/core/zero_point.py:86-183); the float offset goes through
+    _ScaleShiftZeroPoint like every other zero-point"""
 
     def __init__(self, collect_stats_steps: int, int_quant: Module, quantize_zero_point: bool,
                  zero_point_stats_impl: Optional[Module], zero_point_shape: Tuple[int, ...],
                  zero_point_stats_input_view_shape_impl: Module,
                  zero_point_stats_momentum: Optional[float] = DEFAULT_MOMENTUM) -> None:
         super().__init__()
-        assert collect_stats_steps > 0, 'Steps should be more than 0'
-        self.collect_stats_steps = collect_stats_steps
-        self.counter = 0
+        self.bvq_init_collection(collect_stats_steps, zero_point_shape, 0.0, zero_point_stats_momentum)
         self.zero_point_shape = zero_point_shape
         self.stats_input_view_shape_impl = zero_point_stats_input_view_shape_impl
-        self.momentum = zero_point_stats_momentum
-        self.value = Parameter(torch.full(zero_point_shape, 0.0))
-        self.register_buffer('buffer', torch.full(zero_point_shape, 0.0))
         self.zero_point_stats_impl = zero_point_stats_impl
         self.scale_shift_zero_point = _ScaleShiftZeroPoint(int_quant, quantize_zero_point)
 
     def training_forward(self, x) -> Tensor:
         if self.counter < self.collect_stats_steps:
-            stats = self.zero_point_stats_impl(self.stats_input_view_shape_impl(x))
-            stats = stats.view(self.zero_point_shape)
-            new_counter = self.counter + 1
-            if self.counter == 0:
-                inplace_tensor_add(self.buffer, stats.detach())
-            else:
-                inplace_momentum_update(self.buffer, stats.detach(), self.momentum, self.counter, new_counter)
-            self.counter = new_counter
-            return stats + 0. * self.value  # keeps `value` in the graph with a zero gradient (DDP)
+            batch_stat = self.zero_point_stats_impl(self.stats_input_view_shape_impl(x)).view(self.zero_point_shape)
+            self.bvq_fold(batch_stat.detach(), inplace_tensor_add)  # buffer starts at 0: the first fold is a sum
+            return batch_stat + 0. * self.value  # `value` stays in the graph with a zero gradient (DDP)
         if self.counter == self.collect_stats_steps:
-            inplace_tensor_add(self.value.detach(), self.buffer)
-            self.counter = self.counter + 1
+            inplace_tensor_add(self.value.detach(), self.buffer)  # hand over: parameter (0) += average
+            self.counter += 1
         return self.value
 
     def forward(self, x: Tensor, scale: Tensor, bit_width: Tensor) -> Tensor:
         if self.training:
-            out = self.training_forward(x)
-        elif self.counter <= self.collect_stats_steps:
-            out = self.buffer
+            offset = self.training_forward(x)
         else:
-            out = self.value
-        out = abs_binary_sign_grad(out)
-        return self.scale_shift_zero_point(out, scale, bit_width)
-
-    def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
-        out = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
-        del out[prefix + 'buffer']
-        if self.counter == 0:
-            del out[prefix + 'value']
-        elif self.counter <= self.collect_stats_steps:
-            out[prefix + 'value'] = self.buffer
-        return out
-
-    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
-                              error_msgs):
-        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
-                                      error_msgs)
-        value_key = prefix + 'value'
-        missing_keys.remove(prefix + 'buffer')
-        training_key = prefix + 'training'
-        if training_key in missing_keys:
-            missing_keys.remove(training_key)
-        if value_key not in missing_keys:
-            self.counter = self.collect_stats_steps + 1
-        if config.IGNORE_MISSING_KEYS and value_key in missing_keys:
-            missing_keys.remove(value_key)
+            offset = self.buffer if self.counter <= self.collect_stats_steps else self.value
+        return self.scale_shift_zero_point(abs_binary_sign_grad(offset), scale, bit_width)
 
 
-class ParameterZeroPoint(torch.nn.Module):
-    """learned zero-point (:186-258)"""
+class ParameterZeroPoint(TolerantLoad, torch.nn.Module):
+    """learned zero-point (B/core/zero_point.py:186-258)"""
+
+    bvq_float_checkpoint_ok = ('value',)
 
     def __init__(self, zero_point_init: Union[float, torch.Tensor], int_quant: Module, quantize_zero_point: bool,
                  zero_point_shape: Tuple[int, ...] = None) -> None:
         super().__init__()
-        if (isinstance(zero_point_init, Tensor) and zero_point_shape is not None
-                and zero_point_init.shape != SCALAR_SHAPE and zero_point_init.shape != zero_point_shape):
-            raise RuntimeError("zero_point_init.shape is non-scalar and != from zero_point_shape.")
-        zero_point_init = zero_point_init.detach() if isinstance(zero_point_init, Tensor) \
-            else torch.tensor(zero_point_init)
-        if zero_point_init.shape == SCALAR_SHAPE and zero_point_shape is not None:
-            zero_point_init = torch.full(zero_point_shape, zero_point_init)
-        self.value = Parameter(zero_point_init)
+        from brevitas_amd.core.scaling.standalone import _as_parameter_init
+        init = _as_parameter_init(zero_point_init, zero_point_shape, 'zero_point_init')
+        if zero_point_shape is not None and init.shape == SCALAR_SHAPE:
+            init = torch.full(zero_point_shape, init)
+        self.value = Parameter(init)
         self.scale_shift_zero_point = _ScaleShiftZeroPoint(int_quant, quantize_zero_point)
 
     def forward(self, x: Tensor, scale: Tensor, bit_width: Tensor) -> Tensor:
-        out = abs_binary_sign_grad(self.value)
-        return self.scale_shift_zero_point(out, scale, bit_width)
-
-    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
-                              error_msgs):
-        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
-                                      error_msgs)
-        value_key = prefix + 'value'
-        if config.IGNORE_MISSING_KEYS and value_key in missing_keys:
-            missing_keys.remove(value_key)
+        return self.scale_shift_zero_point(abs_binary_sign_grad(self.value), scale, bit_width)
