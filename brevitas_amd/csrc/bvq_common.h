@@ -219,7 +219,7 @@ int default_piece_chunks();
 // every row start of every buffer ptrs[i] (element size elsizes[i]) must stay aligned to
 // min(16, vec * elsize) bytes.
 int pick_vec(int max_vec, int64_t rows, int64_t row_len, const void* const* ptrs, const int* elsizes,
-             int nptr);
+             int nptr, bool ragged_ok = false);
 
 Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, int64_t unit_cap = 0,
                    bool few_rows = false);

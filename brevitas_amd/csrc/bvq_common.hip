@@ -39,7 +39,12 @@ int default_piece_chunks() {
 }
 
 int pick_vec(int max_vec, int64_t rows, int64_t row_len, const void* const* ptrs, const int* elsizes,
-             int nptr) {
+             int nptr, bool ragged_ok) {
+  // ragged_ok: the caller's kernels walk the (< vec) elements after the last full chunk of EVERY row and
+  // tolerate vector accesses that are only element-aligned (gfx9+ under ROCm serves unaligned global
+  // accesses in hardware): rows that are not whole chunks, e.g. 14x14 or 7x7 feature maps in 16-bit types,
+  // still move 16 bytes per lane
+  if (ragged_ok && rows > 1 && row_len >= max_vec && row_len % max_vec != 0) return max_vec;
   int vec = max_vec;
   while (vec > 1) {
     bool ok = (rows == 1) || (row_len % vec == 0);

@@ -221,9 +221,11 @@ __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, cons
       }
     }
   }
-  // ragged end (only the last piece of a single-row tensor can have one)
-  const int64_t i = (int64_t)cur.cpr * VEC + lane;
-  if (u.nrows == 1 && i < u.len) {
+  // ragged ends: the (< VEC) elements after the last full chunk of every row of the unit
+  const int32_t tail = (int32_t)(u.len - (int64_t)cur.cpr * VEC);
+  for (int32_t e = lane; e < u.nrows * tail; e += kWave) {
+    const int32_t tr = e / tail, tk = e - tr * tail;
+    const int64_t i = (int64_t)tr * u.row_stride + (int64_t)cur.cpr * VEC + tk;
     float q;
     const float xf = PRE ? relu_f(to_f<XT>(xp[i])) : to_f<XT>(xp[i]);
     const float r = fwd_elem<CT, RM, ZP0>(xf, div, s, z, qmin, qmax, out_int, mode, q);
@@ -644,8 +646,12 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
     }
     tie_first = first;
   }
-  const int64_t i = (int64_t)cur.cpr * VEC + lane;
-  if (u.nrows == 1 && i < u.len) {
+  // ragged ends: the (< VEC) elements after the last full chunk of every row of the unit
+  const int32_t tail = (int32_t)(u.len - (int64_t)cur.cpr * VEC);
+  for (int32_t e = lane; e < u.nrows * tail; e += kWave) {
+    const int32_t tr = e / tail, tk = e - tr * tail;
+    const int64_t in_row = (int64_t)cur.cpr * VEC + tk;
+    const int64_t i = (int64_t)tr * u.row_stride + in_row;
     const float xraw = to_f<XT>(xp[i]);
     float d = bwd_elem<CT, RM, MODE, ZP0>(PRE ? relu_f(xraw) : xraw, to_f<CT>(gp[i]), div, s, z, qmin, qmax,
                                           clamp_ste, mode, ds_acc, dzp_acc);
@@ -653,11 +659,11 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
     dxp[i] = from_f<XT>(d);
     if constexpr (MODE == kBwdDsTies) {
       if (pre_abs_bits<XT, PRE>(xp[i]) == stat_bits) {
+        const unsigned long long p = (unsigned long long)(u.pos0 + (int64_t)tr * a.t.row_len + in_row);
         if (a.pos_part) {
-          const unsigned long long p = (unsigned long long)(u.pos0 + i);
           tie_first = p < tie_first ? p : tie_first;
         } else {
-          record_tie(a.tie_info, per_channel, u.channel, (unsigned long long)(u.pos0 + i));
+          record_tie(a.tie_info, per_channel, u.channel, p);
         }
       }
     }
@@ -954,7 +960,7 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
   const void* ptrs[3] = {x, y, codes};
   const int els[3] = {dtype_size(d->x_dtype), dtype_size(d->ct_dtype), d->codes_dtype == BVQ_CODES_I32 ? 4 : 1};
   const int full = 16 / dtype_size(d->x_dtype);
-  const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3), full);
+  const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3, true), full);
   QuantArgs a = {};
   a.t = make_tiling(outer, channels, row_len, vec, 0, true);
   a.x = x;
@@ -1179,7 +1185,7 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   const void* ptrs[3] = {x, g, dx};
   const int els[3] = {dtype_size(d->x_dtype), dtype_size(d->ct_dtype), dtype_size(d->x_dtype)};
   const int full = 16 / dtype_size(d->x_dtype);
-  const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3), full);
+  const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3, true), full);
   QuantArgs a = {};
   a.t = make_tiling(outer, channels, row_len, vec, 0, true);
   int64_t mid_off = 0;
@@ -1262,7 +1268,7 @@ extern "C" int bvq_fakequant_bwd_stats(const bvq_quant_desc* d, const void* g, c
   const void* ptrs[3] = {x, g, dx};
   const int els[3] = {dtype_size(d->x_dtype), dtype_size(d->ct_dtype), dtype_size(d->x_dtype)};
   const int full = 16 / dtype_size(d->x_dtype);
-  const int vec = snap_vec(pick_vec(full, d->outer * channels, d->inner, ptrs, els, 3), full);
+  const int vec = snap_vec(pick_vec(full, d->outer * channels, d->inner, ptrs, els, 3, true), full);
   QuantArgs a = {};
   a.t = make_tiling(d->outer, channels, d->inner, vec, 0, true);
   const int64_t pos_off = ((a.t.units * (int64_t)sizeof(float) + 7) / 8) * 8;

@@ -56,10 +56,11 @@ __global__ __launch_bounds__(kBlock) void absmax_kernel(StatArgs a) {
       }
     }
   }
-  // ragged end (single-row units only)
-  const int64_t i = (int64_t)cur.cpr * VEC + lane;
-  if (u.nrows == 1 && i < u.len) {
-    const uint32_t b = pre_abs_bits<T, RELU>(xp[i]);
+  // ragged ends: the (< VEC) elements after the last full chunk of every row of the unit
+  const int32_t tail = (int32_t)(u.len - (int64_t)cur.cpr * VEC);
+  for (int32_t e = lane; e < u.nrows * tail; e += kWave) {
+    const int32_t r = e / tail, k = e - r * tail;
+    const uint32_t b = pre_abs_bits<T, RELU>(xp[(int64_t)r * u.row_stride + (int64_t)cur.cpr * VEC + k]);
     m = b > m ? b : m;
   }
   m = wave_max_u32(m);
@@ -99,9 +100,11 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(StatArgs a) {
       }
     }
   }
-  const int64_t i = (int64_t)cur.cpr * VEC + lane;
-  if (u.nrows == 1 && i < u.len) {
-    const float f = RELU ? relu_f(to_f<T>(xp[i])) : to_f<T>(xp[i]);
+  const int32_t tail = (int32_t)(u.len - (int64_t)cur.cpr * VEC);  // ragged ends of every row
+  for (int32_t e = lane; e < u.nrows * tail; e += kWave) {
+    const int32_t r = e / tail, k = e - r * tail;
+    const T xe = xp[(int64_t)r * u.row_stride + (int64_t)cur.cpr * VEC + k];
+    const float f = RELU ? relu_f(to_f<T>(xe)) : to_f<T>(xe);
     nan |= (f != f) ? 1u : 0u;
     mx = fmaxf(mx, f);
     mn = fminf(mn, f);
@@ -540,14 +543,14 @@ __global__ __launch_bounds__(kBlock) void tie_apply_full_kernel(const void* x, c
 // host side
 // ------------------------------------------------------------------------------------------------
 static Tiling stat_tiling(int dtype, const void* x, const void* dx, int64_t outer, int64_t channels,
-                          int64_t inner, int& vec) {
+                          int64_t inner, int& vec, bool ragged_ok = false) {
   // per-tensor: one row holding everything
   const int64_t t_outer = channels > 1 ? outer : 1;
   const int64_t row_len = channels > 1 ? inner : outer * inner;
   const int full = 16 / dtype_size(dtype);
   const void* ptrs[2] = {x, dx};
   const int els[2] = {dtype_size(dtype), dtype_size(dtype)};
-  vec = pick_vec(full, t_outer * channels, row_len, ptrs, els, 2);
+  vec = pick_vec(full, t_outer * channels, row_len, ptrs, els, 2, ragged_ok);
   vec = vec == full ? full : 1;
   return make_tiling(t_outer, (int32_t)channels, row_len, vec);
 }
@@ -674,7 +677,7 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
   }
   int vec;
   StatArgs a;
-  a.t = stat_tiling(dtype, x, nullptr, outer, channels, inner, vec);
+  a.t = stat_tiling(dtype, x, nullptr, outer, channels, inner, vec, true);
   const int32_t splits = finish_splits(a.t.nob * a.t.ppr);
   const int64_t mid_words = splits > 1 ? channels * (int64_t)splits : 0;
   const int64_t need = 2 * (a.t.units + mid_words) * (int64_t)sizeof(uint32_t);
