@@ -224,6 +224,31 @@ int pick_vec(int max_vec, int64_t rows, int64_t row_len, const void* const* ptrs
 Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, int64_t unit_cap = 0,
                    bool few_rows = false);
 
+// ---- column-mapped decomposition -------------------------------------------------------------------
+// For layouts whose channel axis is last or nearly last (x[outer, channels, inner] with a short `inner`:
+// NHWC activations, [tokens, hidden], 7x7 maps) a "row of one channel" is a few bytes, and the row-mapped
+// units above degenerate into strided single-element accesses.  Here the tensor is rows of
+// L = channels * inner contiguous elements instead; a wave owns a STRIP of columns (one 16-byte chunk
+// per lane) for a block of rows and walks down the rows, so every access is a contiguous run of up to
+// 1 KiB and a lane's channels never change: their scales, reciprocals, running maxima and partial sums
+// live in that lane's registers.  Per-(row block, column) partials are laid out [partial row][L], which is
+// exactly the (nob, channels, ppr = inner) indexing the finishing kernels already use.
+struct ColsPlan {
+  bool ok;
+  int64_t rows;     // outer
+  int64_t L;        // channels * inner
+  int32_t vec;
+  int32_t cps;      // chunks per row
+  int32_t lpr;      // lanes per row (min(cps, 64))
+  int32_t rpp;      // rows one wave pass covers (64 / lpr)
+  int32_t strips;   // column strips of 64 chunks
+  int32_t rb;       // rows per row block (a multiple of rpp)
+  int64_t nrb;      // row blocks
+  int64_t prows;    // partial rows = nrb * rpp
+  int64_t units;    // nrb * strips
+};
+ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner);
+
 static inline unsigned grid_for_units(int64_t units) {
   return (unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock);
 }

@@ -98,6 +98,35 @@ int env_flag(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner) {
+  static const int enabled = env_flag("BVQ_COLS", 1);
+  ColsPlan p = {};
+  const int el = dtype == BVQ_F32 ? 4 : 2;
+  const int vec = 16 / el;
+  // short inner runs only: from 256 bytes per channel row on, the row-mapped units stream well
+  if (!enabled || channels < 2 || inner < 1 || outer < 2 || inner * el >= 256) return p;
+  const int64_t L = channels * inner;
+  if (L % vec != 0 || L / vec > (1 << 30)) return p;
+  p.rows = outer;
+  p.L = L;
+  p.vec = vec;
+  p.cps = (int32_t)(L / vec);
+  p.lpr = p.cps < kWave ? p.cps : kWave;
+  p.rpp = kWave / p.lpr;
+  p.strips = (p.cps + kWave - 1) / kWave;
+  // rows per block: ~16 chunks per lane, and few enough partial rows that one workgroup finishes a channel
+  int64_t rb = 16 * (int64_t)p.rpp;
+  const int64_t max_prows = 4096 / inner > 0 ? 4096 / inner : 1;
+  if (p.rpp > max_prows) return p;
+  while (((outer + rb - 1) / rb) * p.rpp > max_prows) rb *= 2;
+  p.rb = (int32_t)rb;
+  p.nrb = (outer + rb - 1) / rb;
+  p.prows = p.nrb * p.rpp;
+  p.units = p.nrb * p.strips;
+  p.ok = true;
+  return p;
+}
+
 int max_units_per_channel() {
   static int v = [] {
     const char* e = getenv("BVQ_MAX_UNITS_PER_CHANNEL");

@@ -202,6 +202,61 @@ __global__ __launch_bounds__(kBlock) void abs_affine_bwd_kernel(Tiling t, const 
   }
 }
 
+// ---- column-mapped abs-max (ColsPlan in bvq_common.h) -------------------------------------------------
+// a lane keeps one running maximum per column of its chunk and writes them as partial row
+// (row block * rpp + sub row) of the [partial rows][L] array the finishing kernel reduces
+struct ColsStatArgs {
+  ColsPlan p;
+  const void* x;
+  uint32_t* part;  // [prows][L]
+};
+
+template <typename T, bool NT, bool RELU>
+__global__ __launch_bounds__(kBlock) void absmax_cols_kernel(ColsStatArgs a) {
+  constexpr int VEC = elem<T>::vec;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (unit >= a.p.units) return;
+  const int64_t rblk = unit / a.p.strips;
+  const int32_t strip = (int32_t)(unit - rblk * a.p.strips);
+  const int32_t sub = lane / a.p.lpr;                       // which of the rpp rows of a pass
+  const int32_t chunk = strip * kWave + (lane - sub * a.p.lpr);  // column chunk of this lane
+  const bool active = sub < a.p.rpp && chunk < a.p.cps;
+  const int64_t row0 = rblk * a.p.rb + sub;
+  const int64_t row_end = (rblk + 1) * a.p.rb < a.p.rows ? (rblk + 1) * a.p.rb : a.p.rows;
+  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + (int64_t)chunk * VEC;
+  uint32_t m[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) m[k] = 0;
+  if (active) {
+    constexpr int kU = 4;
+    for (int64_t r = row0; r < row_end; r += (int64_t)kU * a.p.rpp) {
+      vec_t<T, VEC> xv[kU];
+      bool ok[kU];
+#pragma unroll
+      for (int j = 0; j < kU; ++j) {
+        const int64_t rr = r + (int64_t)j * a.p.rpp;
+        ok[j] = rr < row_end;
+        xv[j] = load_vec<T, VEC, NT>(xp + (ok[j] ? rr : row0) * a.p.L);
+      }
+#pragma unroll
+      for (int j = 0; j < kU; ++j) {
+        if (ok[j]) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const uint32_t b = pre_abs_bits<T, RELU>(xv[j].v[k]);
+            m[k] = b > m[k] ? b : m[k];
+          }
+        }
+      }
+    }
+    uint32_t* out = a.part + (rblk * a.p.rpp + sub) * a.p.L + (int64_t)chunk * VEC;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) out[k] = m[k];
+  }
+}
+
 __device__ __forceinline__ void store_stat(void* out, int out_dtype, int64_t idx, float v) {
   if (out_dtype == BVQ_F32)
     reinterpret_cast<float*>(out)[idx] = v;
@@ -645,7 +700,9 @@ extern "C" int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer,
   (void)kind;
   const int64_t units = worst_units(dtype, outer, channels, inner);
   const int64_t mid = channels * (int64_t)finish_splits(units / channels + 1);
-  const int64_t partials = 2 * (units + mid) * (int64_t)sizeof(uint32_t);
+  int64_t partials = 2 * (units + mid) * (int64_t)sizeof(uint32_t);
+  const ColsPlan cp = cols_plan(dtype, outer, channels, inner);
+  if (cp.ok && cp.prows * cp.L * (int64_t)sizeof(uint32_t) > partials) partials = cp.prows * cp.L * (int64_t)sizeof(uint32_t);
   const int64_t tie = (channels > 1 ? channels : 2 + kTieCap) * (int64_t)sizeof(int64_t);
   return partials + tie + 256;
 }
@@ -675,6 +732,45 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
     set_error("bvq_stats: null pointer");
     return BVQ_ERR_INVALID;
   }
+  hipStream_t st = (hipStream_t)stream;
+  const bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
+  // channel axis last (or nearly): column-mapped units, same finishing kernel
+  const ColsPlan cp = kind == BVQ_STAT_ABSMAX && (reinterpret_cast<uintptr_t>(x) & 15) == 0
+                          ? cols_plan(dtype, outer, channels, inner)
+                          : ColsPlan{};
+  if (cp.ok) {
+    if (workspace_bytes < cp.prows * cp.L * (int64_t)sizeof(uint32_t)) {
+      set_error("bvq_stats: workspace too small");
+      return BVQ_ERR_WORKSPACE;
+    }
+    ColsStatArgs ca;
+    ca.p = cp;
+    ca.x = x;
+    ca.part = reinterpret_cast<uint32_t*>(workspace);
+    const dim3 grid(grid_for_units(cp.units)), block(kBlock);
+    const bool relu = pre_op == BVQ_PRE_RELU;
+#define BVQ_COLS_STAT(T)                                                  \
+  do {                                                                    \
+    if (relu)                                                             \
+      absmax_cols_kernel<T, false, true><<<grid, block, 0, st>>>(ca);     \
+    else if (nt)                                                          \
+      absmax_cols_kernel<T, true, false><<<grid, block, 0, st>>>(ca);     \
+    else                                                                  \
+      absmax_cols_kernel<T, false, false><<<grid, block, 0, st>>>(ca);    \
+  } while (0)
+    if (dtype == BVQ_F32)
+      BVQ_COLS_STAT(float);
+    else if (dtype == BVQ_BF16)
+      BVQ_COLS_STAT(bf16_t);
+    else
+      BVQ_COLS_STAT(f16_t);
+#undef BVQ_COLS_STAT
+    int rc0 = check_launch("bvq_stats/cols");
+    if (rc0) return rc0;
+    stat_finish_kernel<BVQ_STAT_ABSMAX><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(
+        ca.part, ca.part, out, out_dtype, dtype, cp.prows, (int32_t)channels, inner, ep, nullptr, nullptr);
+    return check_launch("bvq_stats/finish");
+  }
   int vec;
   StatArgs a;
   a.t = stat_tiling(dtype, x, nullptr, outer, channels, inner, vec, true);
@@ -688,8 +784,6 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
   a.x = x;
   a.part_a = reinterpret_cast<uint32_t*>(workspace);
   a.part_b = a.part_a + a.t.units;
-  hipStream_t st = (hipStream_t)stream;
-  const bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
   if (dtype == BVQ_F32)
     launch_stat<float>(kind, pre_op, a, vec, nt, st);
   else if (dtype == BVQ_BF16)
