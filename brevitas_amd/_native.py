@@ -562,7 +562,7 @@ def fakequant_bwd_stats(desc, g, x, scale, zp, stat, scale_dtype, int_threshold,
     deposited on the arg-max elements (and the float32 dscale sums if asked); None if the layout is not covered"""
     dev = require_device(g, x, scale, zp, stat)
     wsb = int(lib.bvq_fakequant_bwd_stats_workspace_bytes(ctypes.byref(desc)))
-    if wsb <= 0:
+    if wsb <= 0 or (x.data_ptr() | g.data_ptr()) & 15:  # (views into the middle of a buffer: the general route)
         return None
     dx = torch.empty_like(x)
     ds = torch.empty(int(desc.channels), dtype=torch.float32, device=dev)

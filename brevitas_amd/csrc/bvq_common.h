@@ -231,8 +231,9 @@ Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, in
 // L = channels * inner contiguous elements instead; a wave owns a STRIP of columns (one 16-byte chunk
 // per lane) for a block of rows and walks down the rows, so every access is a contiguous run of up to
 // 1 KiB and a lane's channels never change: their scales, reciprocals, running maxima and partial sums
-// live in that lane's registers.  Per-(row block, column) partials are laid out [partial row][L], which is
-// exactly the (nob, channels, ppr = inner) indexing the finishing kernels already use.
+// live in that lane's registers.  Per-(row block, column) partials are laid out [partial row][L]; a
+// column-parallel kernel folds the partial rows into one row of L entries (coalesced), and that row is the
+// (nob = 1, channels, ppr = inner) layout the finishing kernels already understand.
 struct ColsPlan {
   bool ok;
   int64_t rows;     // outer

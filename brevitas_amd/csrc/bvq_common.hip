@@ -114,11 +114,13 @@ ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner) {
   p.lpr = p.cps < kWave ? p.cps : kWave;
   p.rpp = kWave / p.lpr;
   p.strips = (p.cps + kWave - 1) / kWave;
-  // rows per block: ~16 chunks per lane, and few enough partial rows that one workgroup finishes a channel
+  // rows per block: at least 16 chunks per lane, and no more than ~8192 units in all -- every unit leaves a
+  // partial row of L entries behind, and those should stay a few percent of the traffic
   int64_t rb = 16 * (int64_t)p.rpp;
-  const int64_t max_prows = 4096 / inner > 0 ? 4096 / inner : 1;
-  if (p.rpp > max_prows) return p;
-  while (((outer + rb - 1) / rb) * p.rpp > max_prows) rb *= 2;
+  const int64_t want_blocks = 8192 / p.strips > 0 ? 8192 / p.strips : 1;
+  const int64_t rows_for_that = (outer + want_blocks - 1) / want_blocks;
+  if (rows_for_that > rb) rb = ((rows_for_that + p.rpp - 1) / p.rpp) * p.rpp;
+  if (rb > (1 << 30)) return p;
   p.rb = (int32_t)rb;
   p.nrb = (outer + rb - 1) / rb;
   p.prows = p.nrb * p.rpp;

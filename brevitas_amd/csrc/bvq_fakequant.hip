@@ -102,12 +102,91 @@ struct DivBf16 {
   __device__ __forceinline__ f2 operator()(f2 a) const { return a * r; }
 };
 
+// the same with one scale per element of a pair (column-mapped kernels: a lane's columns differ in channel)
+struct DivExactV {
+  f2 s;
+  __device__ __forceinline__ f2 operator()(f2 a) const {
+    f2 r = {a.x / s.x, a.y / s.y};
+    return r;
+  }
+};
+struct DivBf16V {
+  f2 r;
+  __device__ __forceinline__ f2 operator()(f2 a) const { return a * r; }
+};
+
 __device__ __forceinline__ bool bf16_scale_ok(float s) {
   const uint32_t sb = __builtin_bit_cast(uint32_t, s);
   return (sb & 0xffffu) == 0u && s >= 6.103515625e-05f && s <= 16384.f;
 }
 // the zero-point is exactly +0.0 (symmetric quantizers): see ZP0 below
 __device__ __forceinline__ bool zp_is_pos_zero(float z) { return __builtin_bit_cast(uint32_t, z) == 0u; }
+
+// ------------------------------------------------------------------------------------------------
+// column-mapped quantizer kernels (ColsPlan, bvq_common.h): channel axis last or nearly last
+// ------------------------------------------------------------------------------------------------
+struct ColsQuantArgs {
+  ColsPlan p;
+  const void* x;
+  const void* g;      // bwd
+  void* y;            // fwd: y, bwd: dx
+  const void* scale;  // [channels]
+  const void* zp;     // [channels] or [1]
+  float* ds_part;                // bwd: [prows][L] or null
+  unsigned long long* pos_part;  // bwd: [prows][L] first position attaining tie_stat, or null
+  const void* tie_stat;          // bwd: [channels] or null
+  unsigned long long* tie_info;  // bwd: [channels] (atomic minimum) or null
+  int64_t inner;
+  int32_t channels;
+  float qmin, qmax;
+  int32_t scale_dtype, zp_dtype, zp_pc, scalar_cast, clamp_ste, round_mode, pre_relu;
+};
+
+// what a lane needs to know about its VEC columns, loaded once per unit
+template <typename T>
+struct ColsLane {
+  static constexpr int VEC = elem<T>::vec;
+  int64_t row0, row_end;
+  int32_t chunk, sub;
+  bool active;
+  int32_t ch[VEC];
+  f2 s2[VEC / 2], z2[VEC / 2];
+  bool fast, zp0;  // wave-uniform: every column's scale suits the bf16 reciprocal / every zero-point is +0
+
+  __device__ __forceinline__ bool init(const ColsQuantArgs& a) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (unit >= a.p.units) return false;
+    const int64_t rblk = unit / a.p.strips;
+    const int32_t strip = (int32_t)(unit - rblk * a.p.strips);
+    sub = lane / a.p.lpr;
+    chunk = strip * kWave + (lane - sub * a.p.lpr);
+    active = sub < a.p.rpp && chunk < a.p.cps;
+    row0 = rblk * a.p.rb + sub;
+    row_end = (rblk + 1) * a.p.rb < a.p.rows ? (rblk + 1) * a.p.rb : a.p.rows;
+    bool ok_fast = true, ok_zp0 = true;
+    float sv[VEC], zv[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int64_t col = active ? (int64_t)chunk * VEC + k : 0;
+      ch[k] = (int32_t)(col / a.inner);
+      sv[k] = load_scalar_as_f(a.scale, a.scale_dtype, ch[k]);
+      zv[k] = load_scalar_as_f(a.zp, a.zp_dtype, a.zp_pc ? ch[k] : 0);
+      if (a.scalar_cast && !a.zp_pc) zv[k] = rnd<T>(zv[k]);
+      ok_fast = ok_fast && bf16_scale_ok(sv[k]);
+      ok_zp0 = ok_zp0 && zp_is_pos_zero(zv[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < VEC / 2; ++k) {
+      s2[k] = f2{sv[2 * k], sv[2 * k + 1]};
+      z2[k] = f2{zv[2 * k], zv[2 * k + 1]};
+    }
+    fast = elem<T>::id == BVQ_BF16 && __builtin_amdgcn_ballot_w64(!ok_fast) == 0;
+    zp0 = sizeof(T) == 2 && __builtin_amdgcn_ballot_w64(!ok_zp0) == 0;
+    return true;
+  }
+};
 
 // This file is compiled twice (brevitas_amd/csrc/build.py): BVQ_PART=1 holds the forward kernels and
 // entry point, BVQ_PART=2 the backward ones -- two translation units build in parallel.
@@ -134,8 +213,8 @@ __device__ __forceinline__ float fwd_elem(float xf, const Div& div, float s, flo
 }
 
 // fwd_elem on a pair of elements (bvq_quant_math.h: packed fp32 / packed bf16 conversion)
-template <typename CT, int RM, bool ZP0, typename Div>
-__device__ __forceinline__ f2 fwd_elem2(f2 xf, const Div& div, float s, float z, float qmin, float qmax,
+template <typename CT, int RM, bool ZP0, typename Div, typename S>
+__device__ __forceinline__ f2 fwd_elem2(f2 xf, const Div& div, S s, S z, float qmin, float qmax,
                                         bool out_int, int mode, f2& q_out) {
   f2 t = rnd2<CT>(div(xf));
   t = ZP0 ? t + 0.f : rnd2<CT>(t + z);
@@ -275,6 +354,69 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
 #undef BVQ_FWD_UNIT
 }
 
+
+template <typename T, int RM, bool NT, bool ZP0, bool FAST>
+__device__ __forceinline__ void cols_fwd_rows(const ColsQuantArgs& a, const ColsLane<T>& ln, float qmin, float qmax) {
+  constexpr int VEC = elem<T>::vec;
+  constexpr int kU = 4;
+  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + (int64_t)ln.chunk * VEC;
+  T* __restrict__ yp = reinterpret_cast<T*>(a.y) + (int64_t)ln.chunk * VEC;
+  f2 r2[VEC / 2];
+#pragma unroll
+  for (int k = 0; k < VEC / 2; ++k) r2[k] = f2{1.0f / ln.s2[k].x, 1.0f / ln.s2[k].y};
+  const int mode = a.round_mode;
+  for (int64_t r = ln.row0; r < ln.row_end; r += (int64_t)kU * a.p.rpp) {
+    vec_t<T, VEC> xv[kU];
+    bool ok[kU];
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      const int64_t rr = r + (int64_t)j * a.p.rpp;
+      ok[j] = rr < ln.row_end;
+      xv[j] = load_vec<T, VEC, NT>(xp + (ok[j] ? rr : ln.row0) * a.p.L);
+    }
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      if (ok[j]) {
+        vec_t<T, VEC> yv;
+#pragma unroll
+        for (int k = 0; k < VEC; k += 2) {
+          f2 xf = widen2<T>(xv[j].v[k], xv[j].v[k + 1]);
+          if (a.pre_relu) xf = relu2(xf);
+          f2 q2, res;
+          if constexpr (FAST)
+            res = fwd_elem2<T, RM, ZP0>(xf, DivBf16V{r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax, false, mode, q2);
+          else
+            res = fwd_elem2<T, RM, ZP0>(xf, DivExactV{ln.s2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax, false, mode, q2);
+          pack2<T>(res, yv.v[k], yv.v[k + 1]);
+        }
+        store_vec<T, VEC, NT>(yp + (r + (int64_t)j * a.p.rpp) * a.p.L, yv);
+      }
+    }
+  }
+}
+
+template <typename T, int RM, bool NT>
+__global__ __launch_bounds__(kBlock) void fakequant_fwd_cols_kernel(ColsQuantArgs a) {
+  ColsLane<T> ln;
+  if (!ln.init(a) || !ln.active) return;
+  const float qmin = rnd<T>(a.qmin), qmax = rnd<T>(a.qmax);
+  if constexpr (elem<T>::id == BVQ_BF16) {
+    if (ln.fast) {
+      if (ln.zp0)
+        cols_fwd_rows<T, RM, NT, true, true>(a, ln, qmin, qmax);
+      else
+        cols_fwd_rows<T, RM, NT, false, true>(a, ln, qmin, qmax);
+      return;
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (ln.zp0) {
+      cols_fwd_rows<T, RM, NT, true, false>(a, ln, qmin, qmax);
+      return;
+    }
+  }
+  cols_fwd_rows<T, RM, NT, false, false>(a, ln, qmin, qmax);
+}
 
 // ------------------------------------------------------------------------------------------------
 // statistic + quantizer in ONE kernel: the channel stays in registers between the two
@@ -505,8 +647,8 @@ __device__ __forceinline__ float bwd_elem(float xf, float gf, const Div& div, fl
 }
 
 // bwd_elem on a pair of elements; the sums are kept as pairs too (added up once per unit)
-template <typename CT, int RM, int MODE, bool ZP0, bool SAME16, typename Div>
-__device__ __forceinline__ f2 bwd_elem2(f2 xf, f2 gf, const Div& div, float s, float z, float qmin, float qmax,
+template <typename CT, int RM, int MODE, bool ZP0, bool SAME16, typename Div, typename S>
+__device__ __forceinline__ f2 bwd_elem2(f2 xf, f2 gf, const Div& div, S s, S z, float qmin, float qmax,
                                         bool clamp_ste, int mode, f2& ds_acc, f2& dzp_acc) {
   const f2 t1 = rnd2<CT>(div(xf));
   const f2 t2 = ZP0 ? t1 + 0.f : rnd2<CT>(t1 + z);
@@ -725,6 +867,112 @@ __global__ __launch_bounds__(kBlock) void fakequant_bwd_kernel(QuantArgs a) {
 }
 
 
+template <typename T, int RM, bool NT, bool ZP0, bool FAST>
+__device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const ColsLane<T>& ln, float qmin, float qmax) {
+  constexpr int VEC = elem<T>::vec;
+  constexpr int kU = 2;
+  constexpr bool kSame16 = sizeof(T) == 2;
+  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + (int64_t)ln.chunk * VEC;
+  const T* __restrict__ gp = reinterpret_cast<const T*>(a.g) + (int64_t)ln.chunk * VEC;
+  T* __restrict__ dxp = reinterpret_cast<T*>(a.y) + (int64_t)ln.chunk * VEC;
+  f2 r2[VEC / 2], ds2[VEC / 2], dz_unused = splat2(0.f);
+  uint32_t sk[VEC], first[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC / 2; ++k) {
+    r2[k] = f2{1.0f / ln.s2[k].x, 1.0f / ln.s2[k].y};
+    ds2[k] = splat2(0.f);
+  }
+  const bool ties = a.tie_stat != nullptr;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    sk[k] = ties ? abs_bits<T>(reinterpret_cast<const T*>(a.tie_stat)[ln.ch[k]]) : 0u;
+    first[k] = ~0u;
+  }
+  const bool clamp_ste = a.clamp_ste != 0;
+  const int mode = a.round_mode;
+  for (int64_t r = ln.row0; r < ln.row_end; r += (int64_t)kU * a.p.rpp) {
+    vec_t<T, VEC> xv[kU], gv[kU];
+    bool ok[kU];
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      const int64_t rr = r + (int64_t)j * a.p.rpp;
+      ok[j] = rr < ln.row_end;
+      const int64_t lo = (ok[j] ? rr : ln.row0) * a.p.L;
+      xv[j] = load_vec<T, VEC, NT>(xp + lo);
+      gv[j] = load_vec<T, VEC, NT>(gp + lo);
+    }
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      if (ok[j]) {
+        const int64_t rr = r + (int64_t)j * a.p.rpp;
+        vec_t<T, VEC> dv;
+#pragma unroll
+        for (int k = 0; k < VEC; k += 2) {
+          const f2 xraw = widen2<T>(xv[j].v[k], xv[j].v[k + 1]);
+          const f2 xin = a.pre_relu ? relu2(xraw) : xraw;
+          const f2 gf = widen2<T>(gv[j].v[k], gv[j].v[k + 1]);
+          f2 d;
+          if constexpr (FAST)
+            d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivBf16V{r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax,
+                                                       clamp_ste, mode, ds2[k / 2], dz_unused);
+          else
+            d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivExactV{ln.s2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin,
+                                                       qmax, clamp_ste, mode, ds2[k / 2], dz_unused);
+          if (a.pre_relu) d = xraw > splat2(0.f) ? d : splat2(0.f);
+          pack2<T>(d, dv.v[k], dv.v[k + 1]);
+        }
+        store_vec<T, VEC, NT>(dxp + rr * a.p.L, dv);
+        if (ties) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const uint32_t b = a.pre_relu ? pre_abs_bits<T, true>(xv[j].v[k]) : pre_abs_bits<T, false>(xv[j].v[k]);
+            const uint32_t rr32 = (uint32_t)rr;
+            first[k] = (b == sk[k] && rr32 < first[k]) ? rr32 : first[k];
+          }
+        }
+      }
+    }
+  }
+  // this lane's partial row of the [prows][L] arrays
+  const int64_t prow = (ln.row0 - ln.sub) / a.p.rb * a.p.rpp + ln.sub;
+  const int64_t base = prow * a.p.L + (int64_t)ln.chunk * VEC;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const float dsk = (k & 1) ? ds2[k / 2].y : ds2[k / 2].x;
+    if (a.ds_part) a.ds_part[base + k] = dsk;
+    if (ties) {
+      const int64_t col = (int64_t)ln.chunk * VEC + k;
+      const unsigned long long pos =
+          first[k] == ~0u ? ~0ull : (unsigned long long)first[k] * (unsigned long long)a.inner + (unsigned long long)(col % a.inner);
+      if (a.pos_part) a.pos_part[base + k] = pos;
+      else if (pos != ~0ull) atomicMin(&a.tie_info[ln.ch[k]], pos);
+    }
+  }
+}
+
+template <typename T, int RM, bool NT>
+__global__ __launch_bounds__(kBlock) void fakequant_bwd_cols_kernel(ColsQuantArgs a) {
+  ColsLane<T> ln;
+  if (!ln.init(a) || !ln.active) return;
+  const float qmin = rnd<T>(a.qmin), qmax = rnd<T>(a.qmax);
+  if constexpr (elem<T>::id == BVQ_BF16) {
+    if (ln.fast) {
+      if (ln.zp0)
+        cols_bwd_rows<T, RM, NT, true, true>(a, ln, qmin, qmax);
+      else
+        cols_bwd_rows<T, RM, NT, false, true>(a, ln, qmin, qmax);
+      return;
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (ln.zp0) {
+      cols_bwd_rows<T, RM, NT, true, false>(a, ln, qmin, qmax);
+      return;
+    }
+  }
+  cols_bwd_rows<T, RM, NT, false, false>(a, ln, qmin, qmax);
+}
+
 // Finish of the stats-scaled backward in ONE launch (per-channel layouts): per channel, sum the units'
 // dscale partials (double, fixed order), take the first position attaining the statistic, turn dscale into
 // the statistic's gradient (the backward of scale = clamp_min_ste(stat) / int_threshold, same rounding
@@ -853,6 +1101,50 @@ static void fill_args(QuantArgs& a, const bvq_quant_desc* d) {
   a.codes_dtype = d->codes_dtype;
 }
 
+// column-mapped route for this call? (channel axis last or nearly last; see ColsPlan)
+static ColsPlan cols_quant_plan(const bvq_quant_desc* d, const void* p0, const void* p1, const void* p2) {
+  ColsPlan none = {};
+  if (!(d->scale_per_channel && d->channels > 1) || d->x_dtype != d->ct_dtype || d->out_kind != BVQ_OUT_DEQUANT)
+    return none;
+  if ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15)
+    return none;
+  return cols_plan(d->x_dtype, d->outer, d->channels, d->inner);
+}
+
+static void fill_cols_args(ColsQuantArgs& a, const ColsPlan& cp, const bvq_quant_desc* d) {
+  a.p = cp;
+  a.inner = d->inner;
+  a.channels = (int32_t)d->channels;
+  a.qmin = d->qmin;
+  a.qmax = d->qmax;
+  a.scale_dtype = d->scale_dtype;
+  a.zp_dtype = d->zp_dtype;
+  a.zp_pc = d->zp_per_channel ? 1 : 0;
+  a.scalar_cast = d->scalar_mode == BVQ_SCALAR_CAST;
+  a.clamp_ste = d->clamp_ste;
+  a.round_mode = d->round_mode;
+  a.pre_relu = d->pre_op == BVQ_PRE_RELU;
+}
+
+#define BVQ_COLS_LAUNCH(KERNEL, a, nt, st)                                                       \
+  do {                                                                                           \
+    const dim3 grid(grid_for_units((a).p.units)), block(kBlock);                                 \
+    const bool rne = (a).round_mode == BVQ_ROUND;                                                \
+    if (d->x_dtype == BVQ_F32) {                                                                 \
+      if (rne && nt) KERNEL<float, BVQ_ROUND, true><<<grid, block, 0, st>>>(a);                  \
+      else if (rne) KERNEL<float, BVQ_ROUND, false><<<grid, block, 0, st>>>(a);                  \
+      else KERNEL<float, kAnyRM, false><<<grid, block, 0, st>>>(a);                              \
+    } else if (d->x_dtype == BVQ_BF16) {                                                         \
+      if (rne && nt) KERNEL<bf16_t, BVQ_ROUND, true><<<grid, block, 0, st>>>(a);                 \
+      else if (rne) KERNEL<bf16_t, BVQ_ROUND, false><<<grid, block, 0, st>>>(a);                 \
+      else KERNEL<bf16_t, kAnyRM, false><<<grid, block, 0, st>>>(a);                             \
+    } else {                                                                                     \
+      if (rne && nt) KERNEL<f16_t, BVQ_ROUND, true><<<grid, block, 0, st>>>(a);                  \
+      else if (rne) KERNEL<f16_t, BVQ_ROUND, false><<<grid, block, 0, st>>>(a);                  \
+      else KERNEL<f16_t, kAnyRM, false><<<grid, block, 0, st>>>(a);                              \
+    }                                                                                            \
+  } while (0)
+
 // instantiated vector widths: 16 bytes of x per lane, or one element (ragged / misaligned rows)
 static int snap_vec(int vec, int full) { return vec == full ? full : 1; }
 
@@ -953,6 +1245,21 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
   if (!x || !scale || !zp || (!y && !codes)) {
     set_error("bvq_fakequant_fwd: null pointer");
     return BVQ_ERR_INVALID;
+  }
+  if (y && !codes) {
+    const ColsPlan cp = cols_quant_plan(d, x, y, nullptr);
+    if (cp.ok) {
+      ColsQuantArgs ca = {};
+      fill_cols_args(ca, cp, d);
+      ca.x = x;
+      ca.y = y;
+      ca.scale = scale;
+      ca.zp = zp;
+      hipStream_t cst = (hipStream_t)stream;
+      const bool cnt = n * (int64_t)(2 * dtype_size(d->x_dtype)) >= nt_threshold_bytes();
+      BVQ_COLS_LAUNCH(fakequant_fwd_cols_kernel, ca, cnt, cst);
+      return check_launch("bvq_fakequant_fwd/cols");
+    }
   }
   int64_t outer, row_len;
   int32_t channels;
@@ -1144,7 +1451,11 @@ extern "C" int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* d) {
   rows_of(d, outer, row_len, channels);
   const int64_t units = bwd_units(d);
   const int64_t mid = channel_sums_mid_bytes(units / channels + 1, channels) + 16;
-  return 2 * units * (int64_t)sizeof(float) + mid + 256;
+  int64_t bytes = 2 * units * (int64_t)sizeof(float) + mid + 256;
+  const ColsPlan cp = cols_quant_plan(d, nullptr, nullptr, nullptr);
+  if (cp.ok && (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(float) + 256 > bytes)
+    bytes = (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(float) + 256;
+  return bytes;
 }
 
 extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const void* x,
@@ -1181,6 +1492,38 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   if (!g || !x || !scale || !zp || !dx) {
     set_error("bvq_fakequant_bwd: null pointer");
     return BVQ_ERR_INVALID;
+  }
+  if (!dzp) {
+    const ColsPlan cp = cols_quant_plan(d, x, g, dx);
+    if (cp.ok) {
+      const int64_t need = dscale ? (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(float) : 0;
+      if (dscale && (!workspace || workspace_bytes < need)) {
+        set_error("bvq_fakequant_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+        return BVQ_ERR_WORKSPACE;
+      }
+      ColsQuantArgs ca = {};
+      fill_cols_args(ca, cp, d);
+      ca.x = x;
+      ca.g = g;
+      ca.y = dx;
+      ca.scale = scale;
+      ca.zp = zp;
+      ca.ds_part = dscale ? reinterpret_cast<float*>(workspace) : nullptr;
+      ca.tie_stat = tie_stat;
+      ca.tie_info = reinterpret_cast<unsigned long long*>(tie_info);
+      const bool cnt = n * (int64_t)(3 * dtype_size(d->x_dtype)) >= nt_threshold_bytes();
+      BVQ_COLS_LAUNCH(fakequant_bwd_cols_kernel, ca, cnt, st);
+      rc = check_launch("bvq_fakequant_bwd/cols");
+      if (rc) return rc;
+      if (dscale) {
+        float* folded = nullptr;
+        launch_cols_fold_sum_min(ca.ds_part, nullptr, cp.prows, cp.L, ca.ds_part + cp.prows * cp.L, nullptr, &folded,
+                                 nullptr, st);
+        launch_channel_sums(folded, nullptr, dscale, nullptr, 1, channels, d->inner, nullptr, st);
+        rc = check_launch("bvq_fakequant_bwd/cols_sum");
+      }
+      return rc;
+    }
   }
   const void* ptrs[3] = {x, g, dx};
   const int els[3] = {dtype_size(d->x_dtype), dtype_size(d->ct_dtype), dtype_size(d->x_dtype)};
@@ -1227,6 +1570,12 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
 
 static bool bwd_stats_supported(const bvq_quant_desc* d, int64_t& units, int64_t& per_channel) {
   if (!(d->scale_per_channel && d->channels > 1) || d->zp_per_channel) return false;
+  const ColsPlan cp = cols_quant_plan(d, nullptr, nullptr, nullptr);
+  if (cp.ok) {  // column-mapped partials: [prows][L] plus their fold [L]
+    units = (cp.prows + cols_fold_scratch_rows()) * cp.L;
+    per_channel = d->inner;
+    return true;
+  }
   units = bwd_units(d);
   per_channel = units / d->channels;
   return per_channel <= kSumSlice;  // one finishing stage
@@ -1265,6 +1614,58 @@ extern "C" int bvq_fakequant_bwd_stats(const bvq_quant_desc* d, const void* g, c
     set_error("bvq_fakequant_bwd_stats: null pointer");
     return BVQ_ERR_INVALID;
   }
+  GstatSrc gs = {};
+  gs.from_dscale = 1;
+  gs.scale_dtype = scale_dtype;
+  gs.quot_dtype = quot_dtype;
+  gs.int_threshold = (float)int_threshold;
+  gs.pre_relu = d->pre_op == BVQ_PRE_RELU;
+  const bool nt =
+      n * (int64_t)(2 * dtype_size(d->x_dtype) + dtype_size(d->ct_dtype)) >= nt_threshold_bytes();
+  {
+    const ColsPlan cp = cols_quant_plan(d, x, g, dx);
+    const ColsPlan sized = cols_quant_plan(d, nullptr, nullptr, nullptr);
+    if (sized.ok && !cp.ok) {
+      set_error("bvq_fakequant_bwd_stats: the column-mapped route needs 16-byte aligned x, g and dx");
+      return BVQ_ERR_UNSUPPORTED;
+    }
+    if (cp.ok) {
+      const int64_t words = (cp.prows + cols_fold_scratch_rows()) * cp.L;
+      const int64_t pos_off_c = ((words * (int64_t)sizeof(float) + 7) / 8) * 8;
+      if (workspace_bytes < pos_off_c + words * (int64_t)sizeof(unsigned long long)) {
+        set_error("bvq_fakequant_bwd_stats: workspace too small");
+        return BVQ_ERR_WORKSPACE;
+      }
+      ColsQuantArgs ca = {};
+      fill_cols_args(ca, cp, d);
+      ca.x = x;
+      ca.g = g;
+      ca.y = dx;
+      ca.scale = scale;
+      ca.zp = zp;
+      ca.ds_part = reinterpret_cast<float*>(workspace);
+      ca.pos_part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + pos_off_c);
+      ca.tie_stat = stat;
+      BVQ_COLS_LAUNCH(fakequant_bwd_cols_kernel, ca, nt, st);
+      rc = check_launch("bvq_fakequant_bwd_stats/cols");
+      if (rc) return rc;
+      float* ds_fold = nullptr;
+      unsigned long long* pos_fold = nullptr;
+      launch_cols_fold_sum_min(ca.ds_part, ca.pos_part, cp.prows, cp.L, ca.ds_part + cp.prows * cp.L,
+                               ca.pos_part + cp.prows * cp.L, &ds_fold, &pos_fold, st);
+      const dim3 fgrid((unsigned)channels), fblock(kBlock);
+      if (d->x_dtype == BVQ_F32)
+        bwd_stats_finish_kernel<float><<<fgrid, fblock, 0, st>>>(ds_fold, pos_fold, dscale, gs, x, dx, 1, channels,
+                                                                 d->inner, d->inner);
+      else if (d->x_dtype == BVQ_BF16)
+        bwd_stats_finish_kernel<bf16_t><<<fgrid, fblock, 0, st>>>(ds_fold, pos_fold, dscale, gs, x, dx, 1, channels,
+                                                                  d->inner, d->inner);
+      else
+        bwd_stats_finish_kernel<f16_t><<<fgrid, fblock, 0, st>>>(ds_fold, pos_fold, dscale, gs, x, dx, 1, channels,
+                                                                 d->inner, d->inner);
+      return check_launch("bvq_fakequant_bwd_stats/cols_finish");
+    }
+  }
   const void* ptrs[3] = {x, g, dx};
   const int els[3] = {dtype_size(d->x_dtype), dtype_size(d->ct_dtype), dtype_size(d->x_dtype)};
   const int full = 16 / dtype_size(d->x_dtype);
@@ -1285,19 +1686,11 @@ extern "C" int bvq_fakequant_bwd_stats(const bvq_quant_desc* d, const void* g, c
   a.y = dx;
   a.tie_stat = stat;
   fill_args(a, d);
-  const bool nt =
-      n * (int64_t)(2 * dtype_size(d->x_dtype) + dtype_size(d->ct_dtype)) >= nt_threshold_bytes();
 #define BVQ_CALL(XT, CT) launch_bwd<XT, CT>(a, vec, kBwdDsTies, nt, st)
   BVQ_DISPATCH_PAIR(d, BVQ_CALL);
 #undef BVQ_CALL
   rc = check_launch("bvq_fakequant_bwd_stats");
   if (rc) return rc;
-  GstatSrc gs = {};
-  gs.from_dscale = 1;
-  gs.scale_dtype = scale_dtype;
-  gs.quot_dtype = quot_dtype;
-  gs.int_threshold = (float)int_threshold;
-  gs.pre_relu = d->pre_op == BVQ_PRE_RELU;
   const dim3 grid((unsigned)channels), block(kBlock);
   if (d->x_dtype == BVQ_F32)
     bwd_stats_finish_kernel<float><<<grid, block, 0, st>>>(a.ds_part, a.pos_part, dscale, gs, x, dx, a.t.nob, channels,

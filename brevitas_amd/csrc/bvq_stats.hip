@@ -702,7 +702,8 @@ extern "C" int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer,
   const int64_t mid = channels * (int64_t)finish_splits(units / channels + 1);
   int64_t partials = 2 * (units + mid) * (int64_t)sizeof(uint32_t);
   const ColsPlan cp = cols_plan(dtype, outer, channels, inner);
-  if (cp.ok && cp.prows * cp.L * (int64_t)sizeof(uint32_t) > partials) partials = cp.prows * cp.L * (int64_t)sizeof(uint32_t);
+  if (cp.ok && (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(uint32_t) > partials)
+    partials = (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(uint32_t);
   const int64_t tie = (channels > 1 ? channels : 2 + kTieCap) * (int64_t)sizeof(int64_t);
   return partials + tie + 256;
 }
@@ -739,7 +740,7 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
                           ? cols_plan(dtype, outer, channels, inner)
                           : ColsPlan{};
   if (cp.ok) {
-    if (workspace_bytes < cp.prows * cp.L * (int64_t)sizeof(uint32_t)) {
+    if (workspace_bytes < (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(uint32_t)) {
       set_error("bvq_stats: workspace too small");
       return BVQ_ERR_WORKSPACE;
     }
@@ -767,8 +768,9 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
 #undef BVQ_COLS_STAT
     int rc0 = check_launch("bvq_stats/cols");
     if (rc0) return rc0;
+    uint32_t* folded = launch_cols_fold_max(ca.part, cp.prows, cp.L, ca.part + cp.prows * cp.L, st);  // [L]
     stat_finish_kernel<BVQ_STAT_ABSMAX><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(
-        ca.part, ca.part, out, out_dtype, dtype, cp.prows, (int32_t)channels, inner, ep, nullptr, nullptr);
+        folded, folded, out, out_dtype, dtype, 1, (int32_t)channels, inner, ep, nullptr, nullptr);
     return check_launch("bvq_stats/finish");
   }
   int vec;

@@ -93,4 +93,78 @@ static inline void launch_channel_sums(const float* part0, const float* part1, f
   }
 }
 
+// Column-mapped partials [prows][L] -> one row [L].  Thread (j, slice) folds column j over the partial rows
+// of its slice (coalesced across j); two launches: prows -> <= kFoldSlices rows -> 1 row.
+// (templates only so that the header can be included by several translation units)
+constexpr int kFoldSlices = 64;
+
+static inline int64_t cols_fold_scratch_rows() { return kFoldSlices + 1; }  // rows of L entries behind the partials
+
+template <int UNUSED>
+__global__ __launch_bounds__(kBlock) void cols_fold_max_kernel(const uint32_t* __restrict__ part, uint32_t* __restrict__ out,
+                                                               int64_t prows, int64_t L, int64_t rows_per_slice) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= L) return;
+  const int64_t o0 = (int64_t)blockIdx.y * rows_per_slice;
+  const int64_t o1 = o0 + rows_per_slice < prows ? o0 + rows_per_slice : prows;
+  uint32_t m = 0;
+  for (int64_t o = o0; o < o1; ++o) {
+    const uint32_t b = part[o * L + j];
+    m = b > m ? b : m;
+  }
+  out[(int64_t)blockIdx.y * L + j] = m;
+}
+
+template <int UNUSED>
+__global__ __launch_bounds__(kBlock) void cols_fold_sum_min_kernel(const float* __restrict__ ds_part,
+                                                                   const unsigned long long* __restrict__ pos_part,
+                                                                   float* __restrict__ ds_out,
+                                                                   unsigned long long* __restrict__ pos_out, int64_t prows,
+                                                                   int64_t L, int64_t rows_per_slice) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= L) return;
+  const int64_t o0 = (int64_t)blockIdx.y * rows_per_slice;
+  const int64_t o1 = o0 + rows_per_slice < prows ? o0 + rows_per_slice : prows;
+  double acc = 0.0;
+  unsigned long long pmin = ~0ull;
+  for (int64_t o = o0; o < o1; ++o) {
+    if (ds_part) acc += (double)ds_part[o * L + j];
+    if (pos_part) {
+      const unsigned long long q = pos_part[o * L + j];
+      pmin = q < pmin ? q : pmin;
+    }
+  }
+  if (ds_part) ds_out[(int64_t)blockIdx.y * L + j] = (float)acc;
+  if (pos_part) pos_out[(int64_t)blockIdx.y * L + j] = pmin;
+}
+
+// scratch: cols_fold_scratch_rows() rows of L entries; returns the final row inside it
+static inline uint32_t* launch_cols_fold_max(const uint32_t* part, int64_t prows, int64_t L, uint32_t* scratch,
+                                             hipStream_t st) {
+  const int64_t slices = prows < kFoldSlices ? prows : kFoldSlices;
+  const int64_t rps = (prows + slices - 1) / slices;
+  const unsigned gx = (unsigned)((L + kBlock - 1) / kBlock);
+  cols_fold_max_kernel<0><<<dim3(gx, (unsigned)slices), dim3(kBlock), 0, st>>>(part, scratch, prows, L, rps);
+  uint32_t* fin = scratch + (int64_t)kFoldSlices * L;
+  cols_fold_max_kernel<0><<<dim3(gx, 1), dim3(kBlock), 0, st>>>(scratch, fin, slices, L, slices);
+  return fin;
+}
+
+static inline void launch_cols_fold_sum_min(const float* ds_part, const unsigned long long* pos_part, int64_t prows,
+                                            int64_t L, float* ds_scratch, unsigned long long* pos_scratch,
+                                            float** ds_final, unsigned long long** pos_final, hipStream_t st) {
+  const int64_t slices = prows < kFoldSlices ? prows : kFoldSlices;
+  const int64_t rps = (prows + slices - 1) / slices;
+  const unsigned gx = (unsigned)((L + kBlock - 1) / kBlock);
+  cols_fold_sum_min_kernel<0><<<dim3(gx, (unsigned)slices), dim3(kBlock), 0, st>>>(ds_part, pos_part, ds_scratch,
+                                                                                   pos_scratch, prows, L, rps);
+  float* dsf = ds_part ? ds_scratch + (int64_t)kFoldSlices * L : nullptr;
+  unsigned long long* posf = pos_part ? pos_scratch + (int64_t)kFoldSlices * L : nullptr;
+  cols_fold_sum_min_kernel<0><<<dim3(gx, 1), dim3(kBlock), 0, st>>>(ds_part ? ds_scratch : nullptr,
+                                                                    pos_part ? pos_scratch : nullptr, dsf, posf, slices, L,
+                                                                    slices);
+  *ds_final = dsf;
+  if (pos_final) *pos_final = posf;
+}
+
 }  // namespace bvq
