@@ -29,6 +29,14 @@ class Plan(NamedTuple):
     scale_pc: bool
     zp_pc: bool
     ct: torch.dtype
+    nhwc: bool = False  # x is a dense channels_last tensor taken in memory order: [N*H*W, C] rows, channel last
+
+
+def is_nhwc(x: Tensor, channel_dim) -> bool:
+    """per-channel (dim 1) quantization of a dense channels_last tensor: its memory IS [N*H*W, C], which the
+    column-mapped kernels take as it lies (no NCHW copy and back)"""
+    return channel_dim == 1 and x.dim() == 4 and not x.is_contiguous() \
+        and x.is_contiguous(memory_format=torch.channels_last)
 
 
 def _channel_dim(x: Tensor, t: Tensor):
@@ -64,6 +72,8 @@ def plan(x: Tensor, scale: Tensor, zp: Tensor) -> Optional[Plan]:
     cd = sd if sd is not None else zd
     if cd is None:
         return Plan(1, 1, x.numel(), False, False, ct)
+    if is_nhwc(x, cd):
+        return Plan(x.numel() // x.shape[1], x.shape[1], 1, sd is not None, zd is not None, ct, True)
     outer = 1
     for s in x.shape[:cd]:
         outer *= s
@@ -91,11 +101,13 @@ def _reduce_like(sums: Tensor, like: Tensor) -> Tensor:
     return sums.reshape(like.shape).to(like.dtype)
 
 
-def _memory_order(x: Tensor, channels: int):
+def _memory_order(x: Tensor, channels: int, nhwc: bool = False):
     """-> (contiguous tensor holding x's elements, permutation that maps a same-ordered result back to x's
     logical layout or None).  A per-tensor quantizer does not care about element order, so a dense
     channels_last tensor (the layout MIOpen prefers) is taken as it lies in memory instead of being copied to
     NCHW and back; every other case is `x.contiguous()` like the reference's own reshape."""
+    if nhwc:
+        return x.permute(0, 2, 3, 1), (0, 3, 1, 2)
     if x.is_contiguous() or channels != 1:
         return x.contiguous(), None
     if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
@@ -124,7 +136,7 @@ class FakeQuantFn(Function):
 
     @staticmethod
     def forward(ctx, x, scale, zp, p, qmin, qmax, round_mode, clamp_ste, out_kind, pre_op=nat.PRE_NONE):
-        xc, back = _memory_order(x, p.channels)
+        xc, back = _memory_order(x, p.channels, p.nhwc)
         sc = scale.reshape(-1).contiguous()
         zc = zp.reshape(-1).contiguous()
         desc = make_desc(p, xc, sc, zc, qmin, qmax, round_mode, clamp_ste, out_kind, pre_op)
@@ -161,6 +173,7 @@ class StatsPlan(NamedTuple):
     scaling_shape: tuple
     min_val: float
     int_threshold: float  # host value of int_scaling_impl(bit_width)
+    nhwc: bool = False    # see Plan.nhwc
 
 
 _ZERO_ZP = {}
@@ -230,7 +243,7 @@ class StatsFakeQuantFn(Function):
     def forward(ctx, x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, group=None, pre_op=nat.PRE_NONE):
         ctx.set_materialize_grads(False)  # an unused `scale` output must not cost a zero-fill + add
         ctx.pre_op = pre_op
-        xc, back = _memory_order(x, sp.channels)
+        xc, back = _memory_order(x, sp.channels, sp.nhwc)
         ctx.back = back
         flat = xc.reshape(-1)
         zp = _zero_zero_point(x.device)
@@ -253,8 +266,8 @@ class StatsFakeQuantFn(Function):
             scale = scale.view(sp.scaling_shape)
         else:
             stat, scale = stats_scale(flat, int_threshold, sp, group, pre_op)
-            p = plan(xc, scale, zp)
-            if p is None:
+            p = Plan(sp.outer, sp.channels, sp.inner, sp.channels > 1, False, torch.result_type(x, scale), sp.nhwc)
+            if not (p.ct == x.dtype or p.ct == torch.float32):
                 raise nat.BvqError('StatsFakeQuantFn: unsupported operand layout (caller must pre-check)')
             sc = scale.reshape(-1).contiguous()
             desc = make_desc(p, xc, sc, zp.reshape(-1), qmin, qmax, round_mode, clamp_ste, nat.OUT_DEQUANT, pre_op)

@@ -134,6 +134,9 @@ class RescalingIntQuant(torch.nn.Module):
         padded = (1,) * (x.dim() - len(shape)) + shape
         if len(shape) > x.dim() or padded != want or x.shape[cd] == 1:
             return None
+        if _fused.is_nhwc(x, cd):  # dense channels_last activation: [N*H*W, C] in memory, column-mapped kernels
+            return _fused.StatsPlan(x.numel() // x.shape[1], x.shape[1], 1, shape, tmpl['min_val'], tmpl['int_thr'],
+                                    True), tmpl
         outer = 1
         for d in x.shape[:cd]:
             outer *= d
@@ -168,8 +171,8 @@ class RescalingIntQuant(torch.nn.Module):
             if fused is not None and fused[1]['runtime'] is not None:
                 sp, tmpl = fused
                 group = getattr(self, 'bvq_shard_group', None)
-                stat, scale = _fused.stats_scale(x.contiguous().reshape(-1), self.int_scaling_impl(bit_width), sp,
-                                                 group, pre_op)
+                flat = _fused._memory_order(x, sp.channels, sp.nhwc)[0].reshape(-1)
+                stat, scale = _fused.stats_scale(flat, self.int_scaling_impl(bit_width), sp, group, pre_op)
                 tmpl['runtime'].update_running_stats(stat.view(sp.scaling_shape))
                 x_act = torch.relu(x) if pre_op == nat.PRE_RELU else x
             else:

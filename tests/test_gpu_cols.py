@@ -117,3 +117,46 @@ def test_cols_mixed_scales_take_the_exact_division_per_wave():
     y_c = nat.fakequant_fwd(d2, x, sb, zp)
     y_r = nat.fakequant_fwd(d2, _misaligned(x), sb, zp)
     assert torch.equal(bits(y_c), bits(y_r))
+
+
+@pytest.mark.parametrize('kind', ['stats_scaled', 'learned_scale'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_channels_last_per_channel_quantizer(kind, dtype):
+    """a per-channel (dim 1) quantizer on a dense channels_last activation runs on its memory as it lies
+    ([N*H*W, C], column-mapped kernels) and returns channels_last tensors: same values as for the NCHW tensor"""
+    import brevitas_amd.quant as Q
+    from brevitas_amd.core.bit_width import BitWidthConst
+    from brevitas_amd.core.function_wrapper import RoundSte, TensorClamp
+    from brevitas_amd.core.quant import IntQuant, RescalingIntQuant
+    from brevitas_amd.core.restrict_val import FloatRestrictValue
+    from brevitas_amd.core.scaling import IntScaling, ParameterScaling
+    from brevitas_amd.core.zero_point import ZeroZeroPoint
+    torch.manual_seed(123456)
+    N, C, H, W = 6, 16, 5, 7
+    x = torch.randn(N, C, H, W, device=DEV).to(dtype)
+    g = torch.randn(N, C, H, W, device=DEV).to(dtype)
+    outs = []
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        if kind == 'stats_scaled':
+            q = Q.Int8ActPerChannelFloat(C).to(DEV)
+        else:
+            q = RescalingIntQuant(
+                IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+                ParameterScaling(torch.rand(1, C, 1, 1) + 0.5, (1, C, 1, 1), FloatRestrictValue(), 1e-10),
+                IntScaling(signed=True, narrow_range=False), ZeroZeroPoint(), BitWidthConst(8)).to(DEV).to(dtype)
+            torch.manual_seed(5)
+            with torch.no_grad():
+                q.scaling_impl.value.copy_((torch.rand(1, C, 1, 1, device=DEV) + 0.5).to(dtype))
+        xi = x.clone().to(memory_format=fmt).requires_grad_(True)
+        y, scale, _, _ = q(xi)
+        y.backward(g.to(memory_format=fmt))
+        if fmt is torch.channels_last:
+            assert y.is_contiguous(memory_format=torch.channels_last)
+            assert xi.grad.is_contiguous(memory_format=torch.channels_last)
+        outs.append((y.detach(), scale.detach(), xi.grad, None if kind == 'stats_scaled' else q.scaling_impl.value.grad))
+    (y0, s0, dx0, dv0), (y1, s1, dx1, dv1) = outs
+    assert torch.equal(bits(y0), bits(y1)) and torch.equal(bits(s0), bits(s1))
+    diff = (bits(dx0) != bits(dx1)).reshape(-1).nonzero().reshape(-1)
+    assert diff.numel() <= (C if kind == 'stats_scaled' else 0)
+    if dv0 is not None:
+        assert torch.allclose(dv0.float(), dv1.float(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-4, atol=1e-3)
