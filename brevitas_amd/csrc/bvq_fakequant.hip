@@ -945,13 +945,14 @@ __device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const Cols
       const unsigned long long pos =
           first[k] == ~0u ? ~0ull : (unsigned long long)first[k] * (unsigned long long)a.inner + (unsigned long long)(col % a.inner);
       if (a.pos_part) a.pos_part[base + k] = pos;
-      else if (pos != ~0ull) atomicMin(&a.tie_info[ln.ch[k]], pos);
+      else if (pos != ~0ull) atomicMin(&a.tie_info[col / a.inner], pos);  // (channel recomputed: keeps ln.ch[] dead in the loop)
     }
   }
 }
 
 template <typename T, int RM, bool NT>
-__global__ __launch_bounds__(kBlock) void fakequant_bwd_cols_kernel(ColsQuantArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void fakequant_bwd_cols_kernel(
+    ColsQuantArgs a) {
   ColsLane<T> ln;
   if (!ln.init(a) || !ln.active) return;
   const float qmin = rnd<T>(a.qmin), qmax = rnd<T>(a.qmax);
