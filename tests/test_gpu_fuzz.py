@@ -1,0 +1,94 @@
+"""Seeded random sweep of the C-ABI hot path against the CPU oracle: shapes chosen to hit every tiling the
+library has (long rows cut into pieces, one row per unit, several rows per unit, ragged rows with 16-byte
+accesses, element-granular rows, column-mapped layouts, single-workgroup one-launch forward), every dtype,
+rounding mode, clamp flavour, bit width, zero-point kind and the fused ReLU.  Bit-exact for the statistic,
+y and dx; the reduced gradients within float32 summation error."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_cabi import ndesc, to_np
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}
+
+
+def _cases(n=72, seed=123456):
+    rng = np.random.RandomState(seed)
+    inner_choices = [1, 2, 3, 7, 8, 12, 16, 25, 49, 64, 100, 196, 200, 392, 1000, 3136, 4608, 9000]
+    out = []
+    for i in range(n):
+        inner = int(inner_choices[rng.randint(len(inner_choices))])
+        channels = int([1, 2, 3, 8, 16, 33, 64][rng.randint(7)])
+        budget = 60000 // max(1, channels * inner)
+        outer = int(max(1, min(budget, [1, 2, 5, 17, 64, 300][rng.randint(6)])))
+        out.append(dict(
+            i=i, outer=outer, channels=channels, inner=inner, dn=['f32', 'bf16', 'f16'][rng.randint(3)],
+            rm=int(rng.randint(5)), clamp_ste=int(rng.randint(2)), pre=int(rng.randint(2)),
+            bits=int([2, 4, 8, 8, 8][rng.randint(5)]), signed=int(rng.randint(2)), narrow=int(rng.randint(2)),
+            zp_kind=['zero', 'zero', 'scalar', 'channel'][rng.randint(4)], seed=int(rng.randint(1 << 30))))
+    return out
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize('c', CASES, ids=lambda c: '%d-%dx%dx%d-%s' % (c['i'], c['outer'], c['channels'], c['inner'], c['dn']))
+def test_random_case_against_oracle(oracle, c):
+    from brevitas_amd import _native as nat
+    O = oracle
+    dt = DT[c['dn']]
+    code = nat.dtype_code(dt)
+    outer, ch, inner = c['outer'], c['channels'], c['inner']
+    g = torch.Generator().manual_seed(c['seed'])
+    x = (torch.randn(outer, ch, inner, generator=g) * 2).to(dt)
+    gr = torch.randn(outer, ch, inner, generator=g).to(dt)
+    if c['signed']:
+        qmin = -(2 ** (c['bits'] - 1)) + (1 if c['narrow'] else 0)
+        qmax = 2 ** (c['bits'] - 1) - 1
+    else:
+        qmin, qmax = 0, 2 ** c['bits'] - 1 - (1 if c['narrow'] else 0)
+    pc = ch > 1
+    xd, gd = x.to(DEV).reshape(-1), gr.to(DEV).reshape(-1)
+    # statistic
+    stat = nat.stats(nat.STAT_ABSMAX, xd, outer if pc else 1, ch if pc else 1, inner if pc else x.numel(), pre_op=c['pre'])
+    xn, _ = O.from_torch(x.reshape(-1))
+    gn, _ = O.from_torch(gr.reshape(-1))
+    lay = (outer, ch, inner) if pc else (1, 1, x.numel())
+    want_stat = O.stats(O.STAT_ABSMAX, xn, code, *lay, pre_op=c['pre'])
+    assert np.array_equal(stat.float().cpu().numpy(), want_stat)
+    scale = (torch.clamp_min(stat.float(), 1e-3) / float(max(abs(qmin), abs(qmax)))).to(dt)
+    if c['zp_kind'] == 'zero':
+        zp = torch.zeros(1)
+    elif c['zp_kind'] == 'scalar':
+        zp = torch.tensor([3.0])
+    else:
+        zp = torch.randint(-3, 4, (ch if pc else 1,)).float()
+    zp_pc = c['zp_kind'] == 'channel' and pc
+    od = O.make_desc(*lay, code, code, code, O.F32, scale_per_channel=pc, zp_per_channel=zp_pc, qmin=float(qmin),
+                     qmax=float(qmax), round_mode=c['rm'], clamp_ste=bool(c['clamp_ste']), pre_op=c['pre'])
+    d = ndesc(nat, od)
+    sn, _ = O.from_torch(scale.cpu().reshape(-1))
+    zn = zp.numpy().astype(np.float32)
+    y_o, codes_o = O.fakequant_fwd(od, xn, sn, zn)
+    dx_o, ds_o, dz_o = O.fakequant_bwd(od, gn, xn, sn, zn)
+    zd = zp.to(DEV)
+    y, codes = nat.fakequant_fwd(d, xd, scale, zd, want_codes=True)
+    assert np.array_equal(to_np(y), y_o), 'y'
+    assert np.array_equal(to_np(codes), codes_o), 'codes'
+    y2 = nat.fakequant_fwd(d, xd, scale, zd)  # the route without codes (column-mapped where applicable)
+    assert np.array_equal(to_np(y2), y_o), 'y (no codes)'
+    dx, ds, dz = nat.fakequant_bwd(d, gd, xd, scale, zd, True, True)
+    assert np.array_equal(to_np(dx), dx_o), 'dx'
+    dx3, ds3, _ = nat.fakequant_bwd(d, gd, xd, scale, zd, True, False)  # no dzp: column-mapped where applicable
+    assert np.array_equal(to_np(dx3), dx_o), 'dx (dscale only)'
+    for got, want, name in ((ds, ds_o, 'dscale'), (ds3, ds_o, 'dscale (no dzp)'), (dz, dz_o, 'dzp')):
+        got = got.double().cpu().numpy().reshape(-1)
+        want = want.astype(np.float64).reshape(-1)
+        if got.size != want.size:
+            got = np.array([got.sum()])
+        ok = np.isfinite(want)
+        mag = np.abs(want[ok]).max() if ok.any() else 0.0
+        lim = {'f32': 2e-4, 'bf16': 2e-2, 'f16': 5e-3}[c['dn']]
+        assert np.all(np.abs(got[ok] - want[ok]) <= lim * (np.abs(want[ok]) + mag + 1.0)), name
