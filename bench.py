@@ -69,27 +69,27 @@ def build_quantizer(channels, per_channel, device, group=None):
 
 
 class KernelTimer:
-    """HIP-event brackets around one named C-ABI call, on the stream it is launched on"""
+    """HIP-event brackets around the named C-ABI calls, on the stream they are launched on"""
 
-    def __init__(self, name):
-        self.name = name
-        self.pairs = []
+    def __init__(self, *names):
+        self.pairs = {n: [] for n in names}
         self.enabled = False
 
     def before(self, name):
-        if self.enabled and name == self.name:
+        if self.enabled and name in self.pairs:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
-            self.pairs.append([ev, None])
+            self.pairs[name].append([ev, None])
 
     def after(self, name):
-        if self.enabled and name == self.name and self.pairs and self.pairs[-1][1] is None:
+        p = self.pairs.get(name)
+        if self.enabled and p and p[-1][1] is None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
-            self.pairs[-1][1] = ev
+            p[-1][1] = ev
 
-    def mean_ms(self):
-        ts = [a.elapsed_time(b) for a, b in self.pairs if b is not None]
+    def mean_ms(self, name):
+        ts = [a.elapsed_time(b) for a, b in self.pairs[name] if b is not None]
         return sum(ts) / len(ts) if ts else None
 
 
@@ -208,7 +208,7 @@ def main():
     q = build_quantizer(shape[1], per_channel, device, group)
     n_elem = x.numel()
 
-    timer = KernelTimer('bvq_fakequant_bwd')
+    timer = KernelTimer('bvq_fakequant_bwd', 'bvq_fakequant_fwd', 'bvq_stats')
     nat.set_kernel_timer(timer)
 
     def step():
@@ -242,7 +242,7 @@ def main():
         b = x.element_size()
         # algorithmic bytes of the backward kernel per launch: read g + read x + write dx
         bwd_bytes = 3 * b * n_elem
-        bwd_ms = timer.mean_ms()
+        bwd_ms = timer.mean_ms('bvq_fakequant_bwd')
         achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -269,6 +269,14 @@ def main():
                          'traffic': traffic, 'algorithmic_bytes_per_launch': bwd_bytes,
                          'avg_launch_ms': round(bwd_ms, 4) if bwd_ms else None},
         }
+        # the other two streaming calls of the step, same method (each bracket includes its launch-bound helpers)
+        calls = {}
+        for key, name, passes in (('statistic', 'bvq_stats', 1), ('forward', 'bvq_fakequant_fwd', 2),
+                                  ('backward', 'bvq_fakequant_bwd', 3)):
+            ms = timer.mean_ms(name)
+            if ms:
+                calls[key] = {'ms': round(ms, 4), 'algorithmic_GBps': round(passes * b * n_elem / (ms * 1e-3) / 1e9, 1)}
+        out['calls'] = calls
         if baseline is not None:
             out['cpu_baseline'] = baseline
         sys.stdout.flush()
