@@ -266,6 +266,95 @@ __device__ __forceinline__ void store_stat(void* out, int out_dtype, int64_t idx
     reinterpret_cast<f16_t*>(out)[idx] = (f16_t)v;
 }
 
+// min/max over the same mapping.  Partials are order-preserving unsigned keys so that the abs-max fold
+// (an unsigned max) serves both: columns [0, L) hold key(max), columns [L, 2L) hold key(-min); a NaN
+// anywhere in a column turns both of its keys into 0xffffffff (torch.max / torch.min propagate NaN).
+__device__ __forceinline__ uint32_t order_key(float f) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, f);
+  return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float order_key_value(uint32_t k) {
+  return __builtin_bit_cast(float, (k >> 31) ? (k ^ 0x80000000u) : ~k);  // 0xffffffff -> a NaN pattern
+}
+
+template <typename T, bool NT, bool RELU>
+__global__ __launch_bounds__(kBlock) void minmax_cols_kernel(ColsStatArgs a) {
+  constexpr int VEC = elem<T>::vec;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (unit >= a.p.units) return;
+  const int64_t rblk = unit / a.p.strips;
+  const int32_t strip = (int32_t)(unit - rblk * a.p.strips);
+  const int32_t sub = lane / a.p.lpr;
+  const int32_t chunk = strip * kWave + (lane - sub * a.p.lpr);
+  const bool active = sub < a.p.rpp && chunk < a.p.cps;
+  const int64_t row0 = rblk * a.p.rb + sub;
+  const int64_t row_end = (rblk + 1) * a.p.rb < a.p.rows ? (rblk + 1) * a.p.rb : a.p.rows;
+  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + (int64_t)chunk * VEC;
+  float mx[VEC], mn[VEC];
+  uint32_t nan = 0;  // bit k: column k saw a NaN
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    mx[k] = -__builtin_inff();
+    mn[k] = __builtin_inff();
+  }
+  if (active) {
+    constexpr int kU = 4;
+    for (int64_t r = row0; r < row_end; r += (int64_t)kU * a.p.rpp) {
+      vec_t<T, VEC> xv[kU];
+      bool ok[kU];
+#pragma unroll
+      for (int j = 0; j < kU; ++j) {
+        const int64_t rr = r + (int64_t)j * a.p.rpp;
+        ok[j] = rr < row_end;
+        xv[j] = load_vec<T, VEC, NT>(xp + (ok[j] ? rr : row0) * a.p.L);
+      }
+#pragma unroll
+      for (int j = 0; j < kU; ++j) {
+        if (ok[j]) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const float f = RELU ? relu_f(to_f<T>(xv[j].v[k])) : to_f<T>(xv[j].v[k]);
+            nan |= (f != f) ? (1u << k) : 0u;
+            mx[k] = fmaxf(mx[k], f);
+            mn[k] = fminf(mn[k], f);
+          }
+        }
+      }
+    }
+    uint32_t* out = a.part + (rblk * a.p.rpp + sub) * (2 * a.p.L) + (int64_t)chunk * VEC;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const bool bad = (nan >> k) & 1u;
+      out[k] = bad ? 0xffffffffu : order_key(mx[k]);
+      out[a.p.L + k] = bad ? 0xffffffffu : order_key(-mn[k]);
+    }
+  }
+}
+
+// folded keys [2][L] -> max[channels], min[channels]: channel c owns columns [c * inner, (c + 1) * inner)
+__global__ __launch_bounds__(kWave) void minmax_cols_finish_kernel(const uint32_t* __restrict__ folded, void* out,
+                                                                   int out_dtype, int32_t channels, int64_t inner) {
+  const int32_t c = blockIdx.x;
+  const int64_t L = (int64_t)channels * inner;
+  uint32_t kx = 0, kn = 0;
+  for (int64_t i = threadIdx.x; i < inner; i += kWave) {
+    const uint32_t a = folded[(int64_t)c * inner + i], b = folded[L + (int64_t)c * inner + i];
+    kx = a > kx ? a : kx;
+    kn = b > kn ? b : kn;
+  }
+  kx = wave_max_u32(kx);
+  kn = wave_max_u32(kn);
+  if (threadIdx.x == 0) {
+    const bool bad = kx == 0xffffffffu || kn == 0xffffffffu;
+    const float qn = __builtin_nanf("");
+    store_stat(out, out_dtype, c, bad ? qn : order_key_value(kx));
+    store_stat(out, out_dtype, (int64_t)channels + c, bad ? qn : -order_key_value(kn));
+  }
+}
+
 // optional epilogue of the abs-max finisher: statistic -> scale in the same launch
 //   thr   = scalar_clamp_min_ste(stat, min_val)      (B/core/restrict_val.py:22-42)
 //   scale = thr / int_threshold                       (B/core/quant/int.py:160)
@@ -702,8 +791,9 @@ extern "C" int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer,
   const int64_t mid = channels * (int64_t)finish_splits(units / channels + 1);
   int64_t partials = 2 * (units + mid) * (int64_t)sizeof(uint32_t);
   const ColsPlan cp = cols_plan(dtype, outer, channels, inner);
-  if (cp.ok && (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(uint32_t) > partials)
-    partials = (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(uint32_t);
+  // (min/max keeps two key rows per partial row)
+  if (cp.ok && (cp.prows + cols_fold_scratch_rows()) * 2 * cp.L * (int64_t)sizeof(uint32_t) > partials)
+    partials = (cp.prows + cols_fold_scratch_rows()) * 2 * cp.L * (int64_t)sizeof(uint32_t);
   const int64_t tie = (channels > 1 ? channels : 2 + kTieCap) * (int64_t)sizeof(int64_t);
   return partials + tie + 256;
 }
@@ -736,11 +826,11 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
   hipStream_t st = (hipStream_t)stream;
   const bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
   // channel axis last (or nearly): column-mapped units, same finishing kernel
-  const ColsPlan cp = kind == BVQ_STAT_ABSMAX && (reinterpret_cast<uintptr_t>(x) & 15) == 0
-                          ? cols_plan(dtype, outer, channels, inner)
-                          : ColsPlan{};
+  const ColsPlan cp =
+      (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? cols_plan(dtype, outer, channels, inner) : ColsPlan{};
   if (cp.ok) {
-    if (workspace_bytes < (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(uint32_t)) {
+    const int64_t width = (kind == BVQ_STAT_MINMAX ? 2 : 1) * cp.L;  // entries per partial row
+    if (workspace_bytes < (cp.prows + cols_fold_scratch_rows()) * width * (int64_t)sizeof(uint32_t)) {
       set_error("bvq_stats: workspace too small");
       return BVQ_ERR_WORKSPACE;
     }
@@ -750,25 +840,38 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
     ca.part = reinterpret_cast<uint32_t*>(workspace);
     const dim3 grid(grid_for_units(cp.units)), block(kBlock);
     const bool relu = pre_op == BVQ_PRE_RELU;
-#define BVQ_COLS_STAT(T)                                                  \
-  do {                                                                    \
-    if (relu)                                                             \
-      absmax_cols_kernel<T, false, true><<<grid, block, 0, st>>>(ca);     \
-    else if (nt)                                                          \
-      absmax_cols_kernel<T, true, false><<<grid, block, 0, st>>>(ca);     \
-    else                                                                  \
-      absmax_cols_kernel<T, false, false><<<grid, block, 0, st>>>(ca);    \
+#define BVQ_COLS_STAT(KERNEL, T)                              \
+  do {                                                        \
+    if (relu)                                                 \
+      KERNEL<T, false, true><<<grid, block, 0, st>>>(ca);     \
+    else if (nt)                                              \
+      KERNEL<T, true, false><<<grid, block, 0, st>>>(ca);     \
+    else                                                      \
+      KERNEL<T, false, false><<<grid, block, 0, st>>>(ca);    \
   } while (0)
-    if (dtype == BVQ_F32)
-      BVQ_COLS_STAT(float);
-    else if (dtype == BVQ_BF16)
-      BVQ_COLS_STAT(bf16_t);
+#define BVQ_COLS_STAT_DT(KERNEL)          \
+  do {                                    \
+    if (dtype == BVQ_F32)                 \
+      BVQ_COLS_STAT(KERNEL, float);       \
+    else if (dtype == BVQ_BF16)           \
+      BVQ_COLS_STAT(KERNEL, bf16_t);      \
+    else                                  \
+      BVQ_COLS_STAT(KERNEL, f16_t);       \
+  } while (0)
+    if (kind == BVQ_STAT_MINMAX)
+      BVQ_COLS_STAT_DT(minmax_cols_kernel);
     else
-      BVQ_COLS_STAT(f16_t);
+      BVQ_COLS_STAT_DT(absmax_cols_kernel);
+#undef BVQ_COLS_STAT_DT
 #undef BVQ_COLS_STAT
     int rc0 = check_launch("bvq_stats/cols");
     if (rc0) return rc0;
-    uint32_t* folded = launch_cols_fold_max(ca.part, cp.prows, cp.L, ca.part + cp.prows * cp.L, st);  // [L]
+    uint32_t* folded = launch_cols_fold_max(ca.part, cp.prows, width, ca.part + cp.prows * width, st);  // [width]
+    if (kind == BVQ_STAT_MINMAX) {
+      minmax_cols_finish_kernel<<<dim3((unsigned)channels), dim3(kWave), 0, st>>>(folded, out, out_dtype,
+                                                                                  (int32_t)channels, inner);
+      return check_launch("bvq_stats/finish");
+    }
     stat_finish_kernel<BVQ_STAT_ABSMAX><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(
         folded, folded, out, out_dtype, dtype, 1, (int32_t)channels, inner, ep, nullptr, nullptr);
     return check_launch("bvq_stats/finish");

@@ -41,6 +41,28 @@ def test_cols_absmax(dn, shape):
         assert torch.equal(bits(st2), bits(want))
 
 
+@pytest.mark.parametrize('dn', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_cols_minmax(dn, shape):
+    """AbsMinMax / NegativeMinOrZero statistics (asymmetric per-channel quantizers) on the same layouts: torch's
+    amax / amin, the row-mapped route on a misaligned copy, NaN poisoning one channel only"""
+    from brevitas_amd import _native as nat
+    outer, ch, inner = shape
+    torch.manual_seed(123457)
+    x = (torch.randn(outer, ch, inner, device=DEV) * 3 + 0.5).to(DT[dn])
+    x[:, 0] = x[:, 0].abs() + 1  # an all-positive and an all-negative channel
+    x[:, 2] = -x[:, 2].abs() - 1
+    for pre in (0, 1):
+        src = torch.relu(x) if pre else x
+        got = nat.stats(nat.STAT_MINMAX, x.reshape(-1), outer, ch, inner, pre_op=pre).view(2, ch)
+        assert torch.equal(got[0], src.amax(dim=(0, 2))) and torch.equal(got[1], src.amin(dim=(0, 2))), pre
+        row = nat.stats(nat.STAT_MINMAX, _misaligned(x), outer, ch, inner, pre_op=pre).view(2, ch)
+        assert torch.equal(bits(got), bits(row)), pre
+    x[outer // 2, 1, inner - 1] = float('nan')
+    got = nat.stats(nat.STAT_MINMAX, x.reshape(-1), outer, ch, inner).view(2, ch)
+    assert torch.isnan(got[:, 1]).all() and not torch.isnan(got[:, 0]).any() and not torch.isnan(got[:, 2:]).any()
+
+
 def _misaligned(t):
     """the same values in a buffer that starts one element off a 16-byte boundary: the library then takes its
     row-mapped route (the column-mapped one needs aligned rows), which is the reference here"""
