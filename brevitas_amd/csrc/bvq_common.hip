@@ -120,7 +120,8 @@ ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner) {
   const int64_t want_blocks = 8192 / p.strips > 0 ? 8192 / p.strips : 1;
   const int64_t rows_for_that = (outer + want_blocks - 1) / want_blocks;
   if (rows_for_that > rb) rb = ((rows_for_that + p.rpp - 1) / p.rpp) * p.rpp;
-  if (rb > (1 << 30)) return p;
+  // a lane's row counter within a unit fits 16 bits (the backward packs it next to a 16-bit key)
+  if (rb > 65000 * (int64_t)p.rpp) rb = 65000 * (int64_t)p.rpp;
   p.rb = (int32_t)rb;
   p.nrb = (outer + rb - 1) / rb;
   p.prows = p.nrb * p.rpp;

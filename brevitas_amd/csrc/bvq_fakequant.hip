@@ -867,27 +867,39 @@ __global__ __launch_bounds__(kBlock) void fakequant_bwd_kernel(QuantArgs a) {
 }
 
 
+#ifndef BVQ_COLS_BWD_UNROLL
+#define BVQ_COLS_BWD_UNROLL 2  // rows in flight per lane
+#endif
+#ifndef BVQ_COLS_BWD_WAVES
+#define BVQ_COLS_BWD_WAVES 4  // occupancy floor handed to the register allocator
+#endif
 template <typename T, int RM, bool NT, bool ZP0, bool FAST>
 __device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const ColsLane<T>& ln, float qmin, float qmax) {
   constexpr int VEC = elem<T>::vec;
-  constexpr int kU = 2;
+  constexpr int kU = BVQ_COLS_BWD_UNROLL;
   constexpr bool kSame16 = sizeof(T) == 2;
   const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + (int64_t)ln.chunk * VEC;
   const T* __restrict__ gp = reinterpret_cast<const T*>(a.g) + (int64_t)ln.chunk * VEC;
   T* __restrict__ dxp = reinterpret_cast<T*>(a.y) + (int64_t)ln.chunk * VEC;
   f2 r2[VEC / 2], ds2[VEC / 2], dz_unused = splat2(0.f);
-  uint32_t sk[VEC], first[VEC];
+  // abs-max tie search: per column, the largest |x| key and the first row that showed it.
+  // 16-bit types: one 32-bit word per column, key << 16 | (0xffff - row counter), so that a single unsigned
+  // max keeps both (ColsPlan bounds a lane's rows per unit by 65535).  float32: strictly-greater updates of
+  // (key, row).  A column whose key equals its channel's statistic reports that row.
+  typedef short i16x2 __attribute__((ext_vector_type(2)));
+  uint32_t um[VEC], first[kSame16 ? 1 : VEC];
 #pragma unroll
   for (int k = 0; k < VEC / 2; ++k) {
     r2[k] = f2{1.0f / ln.s2[k].x, 1.0f / ln.s2[k].y};
     ds2[k] = splat2(0.f);
   }
-  const bool ties = a.tie_stat != nullptr;
 #pragma unroll
-  for (int k = 0; k < VEC; ++k) {
-    sk[k] = ties ? abs_bits<T>(reinterpret_cast<const T*>(a.tie_stat)[ln.ch[k]]) : 0u;
-    first[k] = ~0u;
-  }
+  for (int k = 0; k < VEC; ++k) um[k] = 0u;
+#pragma unroll
+  for (int k = 0; k < (kSame16 ? 1 : VEC); ++k)
+    first[k] = ln.row0 < ln.row_end ? (uint32_t)ln.row0 : ~0u;  // an all-zero column attains its 0 in the first row
+  uint32_t it = 0;  // row counter of this lane (wave-uniform)
+  const bool ties = a.tie_stat != nullptr;
   const bool clamp_ste = a.clamp_ste != 0;
   const int mode = a.round_mode;
   for (int64_t r = ln.row0; r < ln.row_end; r += (int64_t)kU * a.p.rpp) {
@@ -923,35 +935,65 @@ __device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const Cols
         }
         store_vec<T, VEC, NT>(dxp + rr * a.p.L, dv);
         if (ties) {
+          if constexpr (kSame16) {
+            const vec_t<uint32_t, VEC / 2> w = __builtin_bit_cast(vec_t<uint32_t, VEC / 2>, xv[j]);
+            const uint32_t inv = 0xffffu - (it + (uint32_t)j);
 #pragma unroll
-          for (int k = 0; k < VEC; ++k) {
-            const uint32_t b = a.pre_relu ? pre_abs_bits<T, true>(xv[j].v[k]) : pre_abs_bits<T, false>(xv[j].v[k]);
+            for (int k = 0; k < VEC / 2; ++k) {
+              // relu: negative patterns (sign bit set) count as 0; otherwise the sign bits are masked below
+              const uint32_t w2 = a.pre_relu ? __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
+                                                   __builtin_bit_cast(i16x2, w.v[k]), i16x2{0, 0}))
+                                             : w.v[k];
+              const uint32_t klo = ((w2 << 16) & 0x7fff0000u) | inv, khi = (w2 & 0x7fff0000u) | inv;
+              um[2 * k] = klo > um[2 * k] ? klo : um[2 * k];
+              um[2 * k + 1] = khi > um[2 * k + 1] ? khi : um[2 * k + 1];
+            }
+          } else {
             const uint32_t rr32 = (uint32_t)rr;
-            first[k] = (b == sk[k] && rr32 < first[k]) ? rr32 : first[k];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+              const uint32_t b = a.pre_relu ? pre_abs_bits<T, true>(xv[j].v[k]) : pre_abs_bits<T, false>(xv[j].v[k]);
+              const bool gt = b > um[k];
+              um[k] = gt ? b : um[k];
+              first[k] = gt ? rr32 : first[k];
+            }
           }
         }
       }
     }
+    it += kU;
   }
   // this lane's partial row of the [prows][L] arrays
   const int64_t prow = (ln.row0 - ln.sub) / a.p.rb * a.p.rpp + ln.sub;
   const int64_t base = prow * a.p.L + (int64_t)ln.chunk * VEC;
+  if (a.ds_part) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) a.ds_part[base + k] = (k & 1) ? ds2[k / 2].y : ds2[k / 2].x;
+  }
+  if (!ties) return;
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
-    const float dsk = (k & 1) ? ds2[k / 2].y : ds2[k / 2].x;
-    if (a.ds_part) a.ds_part[base + k] = dsk;
-    if (ties) {
-      const int64_t col = (int64_t)ln.chunk * VEC + k;
-      const unsigned long long pos =
-          first[k] == ~0u ? ~0ull : (unsigned long long)first[k] * (unsigned long long)a.inner + (unsigned long long)(col % a.inner);
-      if (a.pos_part) a.pos_part[base + k] = pos;
-      else if (pos != ~0ull) atomicMin(&a.tie_info[col / a.inner], pos);  // (channel recomputed: keeps ln.ch[] dead in the loop)
+    const int64_t col = (int64_t)ln.chunk * VEC + k;
+    const uint32_t sk = abs_bits<T>(reinterpret_cast<const T*>(a.tie_stat)[col / a.inner]);
+    bool hit;
+    unsigned long long row;
+    if constexpr (kSame16) {
+      // (low half 0: no row seen; an all-zero column records its first row, 0 | 0xffff > 0)
+      const uint32_t k16 = um[k] >> 16;
+      hit = (elem<T>::id == BVQ_BF16 ? (k16 << 16) : k16) == sk && (um[k] & 0xffffu) != 0u;
+      row = (unsigned long long)ln.row0 + (unsigned long long)(0xffffu - (um[k] & 0xffffu)) * (unsigned long long)a.p.rpp;
+    } else {
+      hit = um[k] == sk && first[k] != ~0u;
+      row = first[k];
     }
+    const unsigned long long pos = hit ? row * (unsigned long long)a.inner + (unsigned long long)(col % a.inner) : ~0ull;
+    if (a.pos_part) a.pos_part[base + k] = pos;
+    else if (pos != ~0ull) atomicMin(&a.tie_info[col / a.inner], pos);
   }
 }
 
 template <typename T, int RM, bool NT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void fakequant_bwd_cols_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BVQ_COLS_BWD_WAVES, 8))) void fakequant_bwd_cols_kernel(
     ColsQuantArgs a) {
   ColsLane<T> ln;
   if (!ln.init(a) || !ln.active) return;
