@@ -115,6 +115,49 @@ struct DivBf16V {
   __device__ __forceinline__ f2 operator()(f2 a) const { return a * r; }
 };
 
+// DivF16  : the same idea for float16 (11-bit significands): the exact quotient of two float16 values stays
+//           >= 2^-22 (relative) away from every float16 rounding boundary of a NORMAL result, a * RN_f32(1/s)
+//           is within 2^-23 of it.  Subnormal results round on an absolute grid where that argument fails
+//           (254 wrong quotients in 10^8 random pairs, all subnormal), so a quotient with 0 < |q| < 2^-14
+//           (taken with a margin: < 0x38810000) sends the whole wave through the IEEE division -- rare: it
+//           needs |a| < 2^-14 s.  Used by the backward kernels (three divisions per element, VALU-bound
+//           otherwise); scale: a float16 value in [2^-14, 2^14].  tests/test_fastdiv_exact.py checks every
+//           float16 numerator against 5 full binades of scales and a sample of the rest, the GPU test all.
+__device__ __forceinline__ bool f16_quot_small(float q) {
+  return (__builtin_bit_cast(uint32_t, q) & 0x7fffffffu) - 1u < 0x38810000u - 1u;
+}
+struct DivF16 {
+  float s, r;
+  __device__ __forceinline__ float operator()(float a) const {
+    float q = a * r;
+    if (__builtin_amdgcn_ballot_w64(f16_quot_small(q)) != 0) q = a / s;
+    return q;
+  }
+  __device__ __forceinline__ f2 operator()(f2 a) const {
+    f2 q = a * r;
+    if (__builtin_amdgcn_ballot_w64(f16_quot_small(q.x) || f16_quot_small(q.y)) != 0) {
+      q.x = a.x / s;
+      q.y = a.y / s;
+    }
+    return q;
+  }
+};
+struct DivF16V {
+  f2 s, r;
+  __device__ __forceinline__ f2 operator()(f2 a) const {
+    f2 q = a * r;
+    if (__builtin_amdgcn_ballot_w64(f16_quot_small(q.x) || f16_quot_small(q.y)) != 0) {
+      q.x = a.x / s.x;
+      q.y = a.y / s.y;
+    }
+    return q;
+  }
+};
+__device__ __forceinline__ bool f16_scale_ok(float s) {
+  const uint32_t sb = __builtin_bit_cast(uint32_t, s);
+  return (sb & 0x1fffu) == 0u && s >= 6.103515625e-05f && s <= 16384.f;
+}
+
 __device__ __forceinline__ bool bf16_scale_ok(float s) {
   const uint32_t sb = __builtin_bit_cast(uint32_t, s);
   return (sb & 0xffffu) == 0u && s >= 6.103515625e-05f && s <= 16384.f;
@@ -174,7 +217,7 @@ struct ColsLane {
       sv[k] = load_scalar_as_f(a.scale, a.scale_dtype, ch[k]);
       zv[k] = load_scalar_as_f(a.zp, a.zp_dtype, a.zp_pc ? ch[k] : 0);
       if (a.scalar_cast && !a.zp_pc) zv[k] = rnd<T>(zv[k]);
-      ok_fast = ok_fast && bf16_scale_ok(sv[k]);
+      ok_fast = ok_fast && (elem<T>::id == BVQ_F16 ? f16_scale_ok(sv[k]) : bf16_scale_ok(sv[k]));
       ok_zp0 = ok_zp0 && zp_is_pos_zero(zv[k]);
     }
 #pragma unroll
@@ -182,7 +225,7 @@ struct ColsLane {
       s2[k] = f2{sv[2 * k], sv[2 * k + 1]};
       z2[k] = f2{zv[2 * k], zv[2 * k + 1]};
     }
-    fast = elem<T>::id == BVQ_BF16 && __builtin_amdgcn_ballot_w64(!ok_fast) == 0;
+    fast = sizeof(T) == 2 && __builtin_amdgcn_ballot_w64(!ok_fast) == 0;
     zp0 = sizeof(T) == 2 && __builtin_amdgcn_ballot_w64(!ok_zp0) == 0;
     return true;
   }
@@ -854,6 +897,16 @@ __global__ __launch_bounds__(kBlock) void fakequant_bwd_kernel(QuantArgs a) {
       return;
     }
   }
+  if constexpr (elem<CT>::id == BVQ_F16) {
+    if (f16_scale_ok(s)) {
+      const DivF16 div{s, 1.0f / s};
+      if (zp0)
+        BVQ_BWD_PRE(true, div);
+      else
+        BVQ_BWD_PRE(false, div);
+      return;
+    }
+  }
   const DivExact div{s};
   if constexpr (sizeof(CT) == 2) {
     if (zp0) {
@@ -924,7 +977,10 @@ __device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const Cols
           const f2 xin = a.pre_relu ? relu2(xraw) : xraw;
           const f2 gf = widen2<T>(gv[j].v[k], gv[j].v[k + 1]);
           f2 d;
-          if constexpr (FAST)
+          if constexpr (FAST && elem<T>::id == BVQ_F16)
+            d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivF16V{ln.s2[k / 2], r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2],
+                                                       qmin, qmax, clamp_ste, mode, ds2[k / 2], dz_unused);
+          else if constexpr (FAST)
             d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivBf16V{r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax,
                                                        clamp_ste, mode, ds2[k / 2], dz_unused);
           else
@@ -998,7 +1054,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BVQ_COLS
   ColsLane<T> ln;
   if (!ln.init(a) || !ln.active) return;
   const float qmin = rnd<T>(a.qmin), qmax = rnd<T>(a.qmax);
-  if constexpr (elem<T>::id == BVQ_BF16) {
+  if constexpr (sizeof(T) == 2) {
     if (ln.fast) {
       if (ln.zp0)
         cols_bwd_rows<T, RM, NT, true, true>(a, ln, qmin, qmax);

@@ -34,3 +34,38 @@ def test_reciprocal_multiply_is_exact_for_bf16_over_bf16():
             ref = rn_bf16(a / s)
             bad += int(np.count_nonzero(fast != ref))
     assert bad == 0, '%d of %d quotients differ' % (bad, a.size * scales.size)
+
+
+def f16_guard(q):
+    """the kernels' test for `0 < |q| < 2^-14` (with a margin): such quotients take the IEEE division"""
+    ab = q.view(np.uint32) & np.uint32(0x7fffffff)
+    return (ab - np.uint32(1)) < np.uint32(0x38810000 - 1)
+
+
+def f16_scales(full_binades, stride):
+    out = []
+    for e in range(-14, 14):
+        step = 1 if e in full_binades else stride
+        out.extend((1.0 + m / 1024.0) * 2.0 ** e for m in range(0, 1024, step))
+    out.append(2.0 ** 14)
+    return np.array(out, dtype=np.float32)
+
+
+def test_reciprocal_multiply_is_exact_for_f16_over_f16_outside_the_subnormal_guard():
+    """DivF16 (backward kernels): for float16 a and s, RN_f16(a * RN_f32(1/s)) == RN_f16(RN_f32(a / s)) whenever
+    the fast quotient is 0 or at least 2^-14 in magnitude -- every float16 numerator, two full binades of scales
+    and a sample of the others here; tests/test_gpu_fastdiv.py runs all 28 673 scales on the GPU."""
+    a = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    nan = np.isnan(a)
+    bad = guarded = 0
+    with np.errstate(all='ignore'):
+        for s in f16_scales(full_binades=(-14, 0), stride=41):
+            assert np.float32(np.float16(s)) == s
+            q = a * (np.float32(1.0) / s)
+            fast = q.astype(np.float16).view(np.uint16)
+            ref = (a / s).astype(np.float16).view(np.uint16)
+            g = f16_guard(q)
+            bad += int(np.count_nonzero((fast != ref) & ~nan & ~g))
+            guarded += int(np.count_nonzero(g))
+    assert bad == 0
+    assert guarded > 0  # the guard is exercised (it is what makes the subnormal quotients right)

@@ -1,0 +1,64 @@
+"""float16 backward fast path (DivF16, brevitas_amd/csrc/bvq_fakequant.hip): the arithmetic claim on every
+float16 numerator x every float16 scale in [2^-14, 2^14], and the kernels on inputs full of tiny and subnormal
+values (the quotients that must take the IEEE division) against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_cabi import ndesc, to_np
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def test_f16_reciprocal_claim_all_scales():
+    a = torch.arange(65536, dtype=torch.int32, device=DEV).to(torch.int16).view(torch.float16).float()
+    finite = ~torch.isnan(a)
+    scales = torch.arange(0x0400, 0x7400 + 1, dtype=torch.int32, device=DEV).to(torch.int16).view(torch.float16).float()
+    scales = scales[(scales >= 2.0 ** -14) & (scales <= 2.0 ** 14)]
+    assert scales.numel() == 28 * 1024 + 1, scales.numel()
+    bad = 0
+    for chunk in scales.split(512):
+        s = chunk[:, None]
+        q = a[None, :] * (1.0 / s)
+        fast = q.half().view(torch.int16)
+        ref = (a[None, :] / s).half().view(torch.int16)
+        ab = q.view(torch.int32) & 0x7fffffff
+        guard = (ab > 0) & (ab < 0x38810000)
+        bad += int(((fast != ref) & finite[None, :] & ~guard).sum())
+    assert bad == 0, bad
+
+
+@pytest.mark.parametrize('layout', [(8, 16, 3136), (1, 1, 40000), (300, 64, 1), (64, 8, 49)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('zp_kind', ['zero', 'scalar'])
+def test_f16_backward_with_tiny_values(oracle, layout, zp_kind):
+    from brevitas_amd import _native as nat
+    O = oracle
+    outer, ch, inner = layout
+    pc = ch > 1
+    g = torch.Generator().manual_seed(123456 + outer + inner)
+    n = outer * ch * inner
+    x = torch.randn(n, generator=g)
+    gr = torch.randn(n, generator=g)
+    # a third of the elements tiny enough that x / s, (g s) / s or (x / s) / s lands below 2^-14
+    tiny = torch.rand(n, generator=g)
+    x = torch.where(tiny < 0.2, x * 1e-6, x)
+    gr = torch.where((tiny > 0.1) & (tiny < 0.4), gr * 3e-5, gr)
+    x, gr = x.half(), gr.half()
+    code = nat.dtype_code(torch.float16)
+    lay = (outer, ch, inner) if pc else (1, 1, n)
+    xd, gd = x.to(DEV), gr.to(DEV)
+    stat = nat.stats(nat.STAT_ABSMAX, xd, *lay)
+    scale = (stat.float().clamp_min(1e-3) / 127.0).half()
+    zp = torch.zeros(1) if zp_kind == 'zero' else torch.tensor([2.0])
+    od = O.make_desc(*lay, code, code, code, O.F32, scale_per_channel=pc, zp_per_channel=False, qmin=-127.0,
+                     qmax=127.0, round_mode=0, clamp_ste=False, pre_op=0)
+    d = ndesc(nat, od)
+    xn, _ = O.from_torch(x)
+    gn, _ = O.from_torch(gr)
+    sn, _ = O.from_torch(scale.cpu())
+    dx_o, ds_o, _ = O.fakequant_bwd(od, gn, xn, sn, zp.numpy().astype(np.float32))
+    dx, ds, _ = nat.fakequant_bwd(d, gd, xd, scale, zp.to(DEV), True, False)[:3]
+    assert np.array_equal(to_np(dx), dx_o)
+    np.testing.assert_allclose(ds.cpu().numpy().reshape(-1), np.asarray(ds_o).reshape(-1), rtol=2e-4, atol=1e-3)
