@@ -120,8 +120,8 @@ struct DivBf16V {
 //           is within 2^-23 of it.  Subnormal results round on an absolute grid where that argument fails
 //           (254 wrong quotients in 10^8 random pairs, all subnormal), so a quotient with 0 < |q| < 2^-14
 //           (taken with a margin: < 0x38810000) sends the whole wave through the IEEE division -- rare: it
-//           needs |a| < 2^-14 s.  Used by the backward kernels (three divisions per element, VALU-bound
-//           otherwise); scale: a float16 value in [2^-14, 2^14].  tests/test_fastdiv_exact.py checks every
+//           needs |a| < 2^-14 s.  The backward has three divisions per element and was VALU-bound without
+//           it.  Scale: a float16 value in [2^-14, 2^14].  tests/test_fastdiv_exact.py checks every
 //           float16 numerator against 5 full binades of scales and a sample of the rest, the GPU test all.
 __device__ __forceinline__ bool f16_quot_small(float q) {
   return (__builtin_bit_cast(uint32_t, q) & 0x7fffffffu) - 1u < 0x38810000u - 1u;
@@ -385,6 +385,8 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
       return;
     }
   }
+  // (float16: the guarded reciprocal (DivF16) pays in the backward and in the column-mapped forward; here the
+  //  single division hides behind the loads and the extra branch cost 15 %: profiles/r01_f16_fastdiv.txt)
   const DivExact div{s};
   if constexpr (sizeof(CT) == 2) {
     if (zp0) {
@@ -426,7 +428,10 @@ __device__ __forceinline__ void cols_fwd_rows(const ColsQuantArgs& a, const Cols
           f2 xf = widen2<T>(xv[j].v[k], xv[j].v[k + 1]);
           if (a.pre_relu) xf = relu2(xf);
           f2 q2, res;
-          if constexpr (FAST)
+          if constexpr (FAST && elem<T>::id == BVQ_F16)
+            res = fwd_elem2<T, RM, ZP0>(xf, DivF16V{ln.s2[k / 2], r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax, false,
+                                        mode, q2);
+          else if constexpr (FAST)
             res = fwd_elem2<T, RM, ZP0>(xf, DivBf16V{r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax, false, mode, q2);
           else
             res = fwd_elem2<T, RM, ZP0>(xf, DivExactV{ln.s2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax, false, mode, q2);
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_cols_kernel(ColsQuantArg
   ColsLane<T> ln;
   if (!ln.init(a) || !ln.active) return;
   const float qmin = rnd<T>(a.qmin), qmax = rnd<T>(a.qmax);
-  if constexpr (elem<T>::id == BVQ_BF16) {
+  if constexpr (sizeof(T) == 2) {
     if (ln.fast) {
       if (ln.zp0)
         cols_fwd_rows<T, RM, NT, true, true>(a, ln, qmin, qmax);

@@ -32,7 +32,7 @@ def test_f16_reciprocal_claim_all_scales():
 @pytest.mark.parametrize('layout', [(8, 16, 3136), (1, 1, 40000), (300, 64, 1), (64, 8, 49)],
                          ids=lambda s: 'x'.join(map(str, s)))
 @pytest.mark.parametrize('zp_kind', ['zero', 'scalar'])
-def test_f16_backward_with_tiny_values(oracle, layout, zp_kind):
+def test_f16_forward_and_backward_with_tiny_values(oracle, layout, zp_kind):
     from brevitas_amd import _native as nat
     O = oracle
     outer, ch, inner = layout
@@ -58,6 +58,14 @@ def test_f16_backward_with_tiny_values(oracle, layout, zp_kind):
     xn, _ = O.from_torch(x)
     gn, _ = O.from_torch(gr)
     sn, _ = O.from_torch(scale.cpu())
+    y_o, codes_o = O.fakequant_fwd(od, xn, sn, zp.numpy().astype(np.float32))
+    y, codes = nat.fakequant_fwd(d, xd, scale, zp.to(DEV), want_codes=True)
+    assert np.array_equal(to_np(y), y_o) and np.array_equal(to_np(codes), codes_o)
+    assert np.array_equal(to_np(nat.fakequant_fwd(d, xd, scale, zp.to(DEV))), y_o)  # the route without codes
+    if zp_kind == 'zero':
+        one = nat.stats_fakequant_fwd(d, xd, 1e-3, 127.0, torch.float16)  # statistic + quantizer in one launch
+        if one is not None:
+            assert torch.equal(one[1], scale) and np.array_equal(to_np(one[2]), y_o)
     dx_o, ds_o, _ = O.fakequant_bwd(od, gn, xn, sn, zp.numpy().astype(np.float32))
     dx, ds, _ = nat.fakequant_bwd(d, gd, xd, scale, zp.to(DEV), True, False)[:3]
     assert np.array_equal(to_np(dx), dx_o)
