@@ -3,6 +3,8 @@ library has (long rows cut into pieces, one row per unit, several rows per unit,
 accesses, element-granular rows, column-mapped layouts, single-workgroup one-launch forward), every dtype,
 rounding mode, clamp flavour, bit width, zero-point kind and the fused ReLU.  Bit-exact for the statistic,
 y and dx; the reduced gradients within float32 summation error."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -31,7 +33,8 @@ def _cases(n=72, seed=123456):
     return out
 
 
-CASES = _cases()
+# BVQ_FUZZ_CASES / BVQ_FUZZ_SEED widen the sweep for a one-off soak run (the defaults are what the suite runs)
+CASES = _cases(int(os.environ.get('BVQ_FUZZ_CASES', '72')), int(os.environ.get('BVQ_FUZZ_SEED', '123456')))
 
 
 @pytest.mark.parametrize('c', CASES, ids=lambda c: '%d-%dx%dx%d-%s' % (c['i'], c['outer'], c['channels'], c['inner'], c['dn']))
