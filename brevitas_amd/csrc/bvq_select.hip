@@ -12,6 +12,8 @@
 // kernel picks the bin that holds the k-th element.  16-bit types need 2 passes (11 + 5 bits), f32
 // 3 (11 + 11 + 10); after the first pass almost no key matches the prefix, so later passes are pure
 // streaming reads.  Algorithmic bytes per element: passes * sizeof(x).  The result is exact.
+// One-channel (per-tensor) calls of bvq_kth_value take a wider first digit instead -- 15 bits, all 32768 bins in
+// the LDS of one 1024-thread workgroup per CU -- and need one read (|x| of a 16-bit type) or two: see below.
 #include "bvq_common.h"
 #include "bvq_ties.h"
 
@@ -212,6 +214,159 @@ static void launch_hist(const SelArgs& a, int vec, bool nt, hipStream_t st) {
     kth_hist_kernel<T, 1, ABS, false><<<grid, block, 0, st>>>(a);
 }
 
+
+// ---- per-tensor route of bvq_kth_value: 15-bit first digit in LDS, the rest through global counters ----------
+// A workgroup of 1024 threads keeps ALL 32768 bins of the key's top 15 bits in LDS (128 of gfx950's 160 KB).
+//  * |x| of a 16-bit type: that IS the whole key -- one streaming read decides the k-th value, where the digit
+//    passes above read twice; and the keys spread over 16x more bins than an 11-bit digit, which is what the
+//    LDS atomics of that first pass choke on (a bf16 activation puts ~5 % of its elements into the hottest
+//    11-bit bin, 0.3 % into the hottest 15-bit one).
+//  * every other key (16 signed bits, 31 or 32 bits of float32): a second read histograms the remaining
+//    1 / 16 / 17 low bits of the few elements that fell into the chosen bin, straight into global counters
+//    (a wave whose matching lanes all hold the same key adds their count once: constant tensors stay cheap).
+// Two reads instead of three for float32, exact like the digit passes.
+constexpr int kBins15 = 1 << 15;
+constexpr int kBlock15 = 1024;
+constexpr int kLowBitsMax = 17;
+
+__global__ void kth_zero_kernel(uint32_t* p, int32_t n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
+template <typename T, bool ABS, bool NT>
+__global__ __launch_bounds__(kBlock15) void kth_hist15_kernel(const T* __restrict__ x, int64_t n, int32_t shift,
+                                                             uint32_t* __restrict__ hist) {
+  constexpr int VEC = elem<T>::vec;
+  __shared__ uint32_t h[kBins15];
+  for (int b = threadIdx.x; b < kBins15; b += kBlock15) h[b] = 0;
+  __syncthreads();
+  const int64_t chunks = n / VEC;
+  const int64_t stride = (int64_t)gridDim.x * kBlock15;
+  for (int64_t c = (int64_t)blockIdx.x * kBlock15 + threadIdx.x; c < chunks; c += stride * kSelUnroll) {
+    vec_t<T, VEC> xv[kSelUnroll];
+    bool ok[kSelUnroll];
+#pragma unroll
+    for (int j = 0; j < kSelUnroll; ++j) {
+      const int64_t cj = c + (int64_t)j * stride;
+      ok[j] = cj < chunks;
+      if (ok[j]) xv[j] = load_vec<T, VEC, NT>(x + cj * VEC);
+    }
+#pragma unroll
+    for (int j = 0; j < kSelUnroll; ++j) {
+      if (ok[j]) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) atomicAdd(&h[sel_key<T, ABS>(xv[j].v[k]) >> shift], 1u);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && chunks * VEC + threadIdx.x < n)  // the < VEC elements after the last chunk
+    atomicAdd(&h[sel_key<T, ABS>(x[chunks * VEC + threadIdx.x]) >> shift], 1u);
+  __syncthreads();
+  for (int b = threadIdx.x; b < kBins15; b += kBlock15) {
+    const uint32_t c = h[b];
+    if (c) atomicAdd(&hist[b], c);
+  }
+}
+
+// second read: low `shift` bits of the keys whose top 15 bits equal sel[0]
+__device__ __forceinline__ void low_count(uint32_t key, uint32_t want, int32_t shift, uint32_t lowmask,
+                                          uint32_t* __restrict__ ghist) {
+  if ((key >> shift) == want) {
+    const uint32_t low = key & lowmask;
+    const uint32_t first = __builtin_amdgcn_readfirstlane(low);
+    const uint64_t active = __builtin_amdgcn_ballot_w64(true);
+    if (__builtin_amdgcn_ballot_w64(low != first) == 0) {
+      if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(active)) atomicAdd(&ghist[first], (uint32_t)__builtin_popcountll(active));
+    } else {
+      atomicAdd(&ghist[low], 1u);
+    }
+  }
+}
+
+// SMALL: at most 11 low bits (the last bit of a signed 16-bit key): the matching elements of a workgroup meet in
+// an LDS histogram first -- with 2 bins, one global atomic per element would be ~10^4 serialized updates of
+// the same two addresses
+template <typename T, bool ABS, bool NT, bool SMALL>
+__global__ __launch_bounds__(kBlock) void kth_low_kernel(const T* __restrict__ x, int64_t n, int32_t shift,
+                                                        const uint32_t* __restrict__ sel, uint32_t* __restrict__ gh) {
+  constexpr int VEC = elem<T>::vec;
+  __shared__ uint32_t lh[SMALL ? kBins : 1];
+  if constexpr (SMALL) {
+    for (int b = threadIdx.x; b < (1 << shift); b += kBlock) lh[b] = 0;
+    __syncthreads();
+  }
+  uint32_t* ghist = SMALL ? lh : gh;
+  const uint32_t want = sel[0];
+  const uint32_t lowmask = (1u << shift) - 1u;
+  const int64_t chunks = n / VEC;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < chunks; c += stride * kSelUnroll) {
+    vec_t<T, VEC> xv[kSelUnroll];
+    bool ok[kSelUnroll];
+#pragma unroll
+    for (int j = 0; j < kSelUnroll; ++j) {
+      const int64_t cj = c + (int64_t)j * stride;
+      ok[j] = cj < chunks;
+      if (ok[j]) xv[j] = load_vec<T, VEC, NT>(x + cj * VEC);
+    }
+#pragma unroll
+    for (int j = 0; j < kSelUnroll; ++j) {
+      if (ok[j]) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) low_count(sel_key<T, ABS>(xv[j].v[k]), want, shift, lowmask, ghist);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && chunks * VEC + threadIdx.x < n)
+    low_count(sel_key<T, ABS>(x[chunks * VEC + threadIdx.x]), want, shift, lowmask, ghist);
+  if constexpr (SMALL) {
+    __syncthreads();
+    for (int b = threadIdx.x; b < (1 << shift); b += kBlock) {
+      const uint32_t c = lh[b];
+      if (c) atomicAdd(&gh[b], c);
+    }
+  }
+}
+
+// one workgroup: the bin of hist[0, nbins) that holds the k-th (1-indexed) element; sel[0] <- sel[0] << bits | bin
+// (sel[0] starts at 0), krem[0] <- rank inside that bin.  first: k comes as an argument, else from krem[0].
+__global__ __launch_bounds__(kBlock15) void kth_pick_wide_kernel(const uint32_t* __restrict__ hist, int32_t nbins,
+                                                                int32_t bits, int32_t first, int64_t k_arg,
+                                                                uint32_t* __restrict__ sel, int64_t* __restrict__ krem) {
+  __shared__ int64_t part[kBlock15];
+  __shared__ int64_t before_me[kBlock15];
+  const int per = (nbins + kBlock15 - 1) / kBlock15;
+  const int lo = threadIdx.x * per, hi = lo + per < nbins ? lo + per : nbins;
+  int64_t mine = 0;
+  for (int b = lo; b < hi; ++b) mine += hist[b];
+  part[threadIdx.x] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    for (int t = 0; t < kBlock15; ++t) {
+      before_me[t] = run;
+      run += part[t];
+    }
+  }
+  __syncthreads();
+  const int64_t k = first ? k_arg : krem[0];
+  const uint32_t prev = first ? 0u : sel[0];
+  __syncthreads();  // everyone has read krem / sel before the owner overwrites them
+  int64_t run = before_me[threadIdx.x];
+  if (k > run && k <= run + mine) {
+    for (int b = lo; b < hi; ++b) {
+      const int64_t cnt = hist[b];
+      if (k <= run + cnt) {
+        sel[0] = (prev << bits) | (uint32_t)b;
+        krem[0] = k - run;
+        break;
+      }
+      run += cnt;
+    }
+  }
+}
+
 }  // namespace bvq
 
 using namespace bvq;
@@ -227,9 +382,19 @@ struct SelWorkspace {
   int64_t hist_words;
 };
 
-static int64_t sel_workspace_bytes(int dtype, int64_t channels) {
+static int64_t sel_steps_bytes(int dtype, int64_t channels) {
   return (int64_t)passes_for(dtype) * channels * kBins * (int64_t)sizeof(uint32_t) +
          channels * (int64_t)(sizeof(uint32_t) + sizeof(int64_t)) + 256;
+}
+
+// (+ the per-tensor route of bvq_kth_value behind the stepwise layout: 32768 + 2^17 counters, key, rank)
+static int64_t sel_wide_bytes() {
+  return ((int64_t)kBins15 + ((int64_t)1 << kLowBitsMax)) * (int64_t)sizeof(uint32_t) + 64;
+}
+
+static int64_t sel_workspace_bytes(int dtype, int64_t channels) {
+  const int64_t base = (sel_steps_bytes(dtype, channels) + 255) / 256 * 256;
+  return base + (channels == 1 ? sel_wide_bytes() : 0);
 }
 
 static SelWorkspace sel_workspace(int dtype, int64_t channels, void* workspace) {
@@ -409,6 +574,60 @@ extern "C" int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t oute
   if (!x || !out || !workspace) {
     set_error("bvq_kth_value: null pointer");
     return BVQ_ERR_INVALID;
+  }
+  static const int wide = env_flag("BVQ_KTH_WIDE", 1);
+  if (wide && channels == 1 && per_channel >= ((int64_t)1 << 22) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    if (workspace_bytes < sel_workspace_bytes(dtype, channels)) {
+      set_error("bvq_kth_value: workspace too small");
+      return BVQ_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* base = reinterpret_cast<char*>(workspace) + (sel_steps_bytes(dtype, channels) + 255) / 256 * 256;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(base);                   // [32768]
+    uint32_t* low = hist + kBins15;                                       // [1 << shift]
+    int64_t* krem = reinterpret_cast<int64_t*>(low + ((int64_t)1 << kLowBitsMax));
+    uint32_t* sel = reinterpret_cast<uint32_t*>(krem + 1);
+    const int key_bits = (dtype == BVQ_F32 ? 32 : 16) - (abs_key ? 1 : 0);
+    const int shift = key_bits - 15;  // 0, 1, 16 or 17 low bits left for the second read
+    const int32_t words = kBins15 + (shift ? (1 << shift) : 0);
+    kth_zero_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(hist, words);
+    const bool nt = per_channel * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
+    // one workgroup per CU is all the LDS allows; 256 of them cover the chip
+#define BVQ_WIDE(T, ABS)                                                                                               \
+  do {                                                                                                                 \
+    const T* xp = reinterpret_cast<const T*>(x);                                                                       \
+    if (nt)                                                                                                            \
+      kth_hist15_kernel<T, ABS, true><<<dim3(256), dim3(kBlock15), 0, st>>>(xp, per_channel, shift, hist);            \
+    else                                                                                                               \
+      kth_hist15_kernel<T, ABS, false><<<dim3(256), dim3(kBlock15), 0, st>>>(xp, per_channel, shift, hist);           \
+    kth_pick_wide_kernel<<<dim3(1), dim3(kBlock15), 0, st>>>(hist, kBins15, 15, 1, k, sel, krem);                      \
+    if (shift) {                                                                                                       \
+      if (shift <= kDigitBits)                                                                                         \
+        kth_low_kernel<T, ABS, false, true><<<dim3(1024), dim3(kBlock), 0, st>>>(xp, per_channel, shift, sel, low);   \
+      else if (nt)                                                                                                     \
+        kth_low_kernel<T, ABS, true, false><<<dim3(2048), dim3(kBlock), 0, st>>>(xp, per_channel, shift, sel, low);   \
+      else                                                                                                             \
+        kth_low_kernel<T, ABS, false, false><<<dim3(2048), dim3(kBlock), 0, st>>>(xp, per_channel, shift, sel, low);  \
+      kth_pick_wide_kernel<<<dim3(1), dim3(kBlock15), 0, st>>>(low, 1 << shift, shift, 0, 0, sel, krem);               \
+    }                                                                                                                  \
+    kth_store_kernel<T, ABS><<<dim3(1), dim3(64), 0, st>>>(sel, out, 1);                                               \
+  } while (0)
+#define BVQ_WIDE_DT(ABS)       \
+  do {                         \
+    if (dtype == BVQ_F32)      \
+      BVQ_WIDE(float, ABS);    \
+    else if (dtype == BVQ_BF16) \
+      BVQ_WIDE(bf16_t, ABS);   \
+    else                       \
+      BVQ_WIDE(f16_t, ABS);    \
+  } while (0)
+    if (abs_key)
+      BVQ_WIDE_DT(true);
+    else
+      BVQ_WIDE_DT(false);
+#undef BVQ_WIDE_DT
+#undef BVQ_WIDE
+    return check_launch("bvq_kth_value/wide");
   }
   int rc = bvq_kth_begin(dtype, channels, BVQ_KTH_EXPLICIT, k, 0.0, workspace, workspace_bytes, stream);
   for (int p = 0; !rc && p < passes_for(dtype); ++p) {

@@ -234,8 +234,9 @@ int bvq_abs_affine_bwd(int dtype, const void* x, const float* a, const float* b,
  * k-th smallest value (k is 1-indexed, the same for every channel) of |x| (abs_key = 1) or of x
  * (abs_key = 0) over the `outer` and `inner` axes of x[outer, channels, inner]: torch.kthvalue on the
  * flat tensor / along dim 1 of the [C, -1] view, as used by AbsPercentile, NegativePercentileOrZero and
- * PercentileInterval (B/core/stats/stats_op.py:41-126).  Exact selection (MSD radix select: 2 streaming
- * reads of x for 16-bit types, 3 for float32); NaNs order last.  out: dtype of x, `channels` elements. */
+ * PercentileInterval (B/core/stats/stats_op.py:41-126).  Exact selection (MSD radix select); NaNs order last.
+ * Streaming reads of x: channels == 1 (>= 4M elements, 16-byte aligned): 1 for |x| of a 16-bit type, else 2;
+ * otherwise 2 for 16-bit types, 3 for float32.  out: dtype of x, `channels` elements. */
 int64_t bvq_kth_workspace_bytes(int dtype, int64_t outer, int64_t channels, int64_t inner);
 int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
                   int64_t k, void* out, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
