@@ -163,6 +163,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--workload', default='act_per_channel_bf16', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--timer-stride', type=int, default=8,
+                    help='record the per-call HIP events on every n-th timed step (1: every step)')
     ap.add_argument('--shard-path', action='store_true',
                     help='developer option: run the batch-sharded code path (RCCL collectives included) even with one '
                          'rank, to measure its fixed per-step overhead on a single GPU')
@@ -224,9 +226,11 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    timer.enabled = True
+    # the per-call HIP events are recorded on every `timer_stride`-th step only: each record is a barrier packet
+    # in the queue and costs the GPU ~5 us of idle time (profiles/r01_gap_analysis.txt)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        timer.enabled = i % args.timer_stride == 0
         step()
     barrier()
     elapsed = time.perf_counter() - t0
