@@ -456,7 +456,8 @@ extern "C" int bvq_kth_begin(int dtype, int64_t channels, int rule, int64_t k, d
   }
   hipStream_t st = (hipStream_t)stream;
   const SelWorkspace w = sel_workspace(dtype, channels, workspace);
-  (void)hipMemsetAsync(w.hist, 0, (size_t)w.hist_words * sizeof(uint32_t), st);
+  // (a kernel, not hipMemsetAsync: every step of the select is then an ordinary launch under graph capture)
+  kth_zero_kernel<<<dim3((unsigned)((w.hist_words + 255) / 256)), dim3(256), 0, st>>>(w.hist, (int32_t)w.hist_words);
   kth_init_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, st>>>(
       w.prefix, w.krem, rule == BVQ_KTH_EXPLICIT ? k : 0, (int32_t)channels);
   return check_launch("bvq_kth_begin");

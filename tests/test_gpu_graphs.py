@@ -76,3 +76,23 @@ def test_activation_quantizer_step_in_a_graph():
     y.backward(g)
     assert torch.equal(y_s, y) and torch.equal(dx_s, x.grad)
     assert torch.equal(qa.scaling_impl.runtime_stats.running_stats, qb.scaling_impl.runtime_stats.running_stats)
+
+
+@pytest.mark.parametrize('case', [('bf16', 1, 1 << 22, True), ('f32', 1, 1 << 22, False), ('bf16', 1, 50_000, True),
+                                  ('f32', 16, 40_000, True)], ids=lambda c: '%s-%dch-%d' % c[:3])
+def test_percentile_select_in_a_graph(case):
+    """both routes of bvq_kth_value (15-bit LDS digit for big per-tensor inputs, 11-bit digit passes otherwise)
+    are plain launches: captured once, replayed on new data, same bits as the eager call"""
+    from brevitas_amd import _native as nat
+    dn, ch, inner, abs_key = case
+    dt = {'bf16': torch.bfloat16, 'f32': torch.float32}[dn]
+    x = torch.randn(ch * inner, device=DEV).to(dt)
+    k = int(0.999 * inner)
+    graph, out = _capture(lambda: nat.kth_value(x, k, 1, ch, inner, abs_key))
+    for seed in (1, 2):
+        x.copy_((torch.randn(ch * inner, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed)) * 2).to(dt))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, nat.kth_value(x, k, 1, ch, inner, abs_key))
+        ref = (x.abs() if abs_key else x).view(ch, inner).float().kthvalue(k, dim=1)[0]
+        assert torch.equal(out.float(), ref)
