@@ -95,3 +95,41 @@ def test_random_case_against_oracle(oracle, c):
         mag = np.abs(want[ok]).max() if ok.any() else 0.0
         lim = {'f32': 2e-4, 'bf16': 2e-2, 'f16': 5e-3}[c['dn']]
         assert np.all(np.abs(got[ok] - want[ok]) <= lim * (np.abs(want[ok]) + mag + 1.0)), name
+
+
+def _stat_cases(n=48, seed=4242):
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        inner = int([1, 2, 3, 7, 8, 16, 49, 64, 100, 196, 1000, 3136, 9000][rng.randint(13)])
+        channels = int([1, 2, 3, 8, 16, 33, 64, 512][rng.randint(8)])
+        budget = 200000 // max(1, channels * inner)
+        outer = int(max(1, min(budget, [1, 2, 5, 17, 64, 300, 2000][rng.randint(7)])))
+        out.append(dict(i=i, outer=outer, channels=channels, inner=inner, dn=['f32', 'bf16', 'f16'][rng.randint(3)],
+                        pre=int(rng.randint(2)), seed=int(rng.randint(1 << 30)), k_frac=float(rng.rand())))
+    return out
+
+
+@pytest.mark.parametrize('c', _stat_cases(), ids=lambda c: '%d-%dx%dx%d-%s' % (c['i'], c['outer'], c['channels'], c['inner'], c['dn']))
+def test_random_statistics_against_torch(c):
+    """min/max, abs-max and the k-th value on the same random layouts (row-mapped, ragged, column-mapped) against
+    torch's own reductions, which are exact"""
+    from brevitas_amd import _native as nat
+    dt = DT[c['dn']]
+    outer, ch, inner = c['outer'], c['channels'], c['inner']
+    g = torch.Generator().manual_seed(c['seed'])
+    x = (torch.randn(outer, ch, inner, generator=g) * 2 + 0.3).to(dt).to(DEV)
+    src = torch.relu(x) if c['pre'] else x
+    flat = x.reshape(-1)
+    mm = nat.stats(nat.STAT_MINMAX, flat, outer, ch, inner, pre_op=c['pre']).view(2, ch)
+    assert torch.equal(mm[0], src.amax(dim=(0, 2))) and torch.equal(mm[1], src.amin(dim=(0, 2)))
+    am = nat.stats(nat.STAT_ABSMAX, flat, outer, ch, inner, pre_op=c['pre'])
+    assert torch.equal(am, src.abs().amax(dim=(0, 2)))
+    whole = nat.stats(nat.STAT_MINMAX, flat, 1, 1, flat.numel(), pre_op=c['pre'])
+    assert whole[0] == src.max() and whole[1] == src.min()
+    per = outer * inner
+    k = max(1, min(per, int(c['k_frac'] * per) + 1))
+    for abs_key in (True, False):
+        got = nat.kth_value(flat, k, outer, ch, inner, abs_key)
+        v = (x.abs() if abs_key else x).permute(1, 0, 2).reshape(ch, per).float()
+        assert torch.equal(got.float(), v.kthvalue(k, dim=1)[0]), abs_key
