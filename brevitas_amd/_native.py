@@ -35,7 +35,7 @@ EXPORTS = (
     'bvq_abi_version', 'bvq_last_error', 'bvq_unary', 'bvq_stats_pre', 'bvq_scalar_clamp', 'bvq_tensor_clamp',
     'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
     'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_scale_from_stat', 'bvq_shard_pack', 'bvq_shard_unpack', 'bvq_abs_moments_workspace_bytes', 'bvq_abs_moments',
-    'bvq_abs_affine_bwd', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_passes',
+    'bvq_abs_affine_bwd', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_pair', 'bvq_kth_passes',
     'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd', 'bvq_set_fused_max_team',
     'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd_stats_workspace_bytes', 'bvq_fakequant_bwd_stats', 'bvq_fakequant_bwd')
 
@@ -92,6 +92,7 @@ def _load(path=None):
         'bvq_abs_affine_bwd': (i32, [i32, vp, vp, vp, vp, i64, i64, i64, vp]),
         'bvq_kth_workspace_bytes': (i64, [i32, i64, i64, i64]),
         'bvq_kth_value': (i32, [i32, i32, vp, i64, i64, i64, i64, vp, vp, i64, vp]),
+        'bvq_kth_pair': (i32, [i32, i32, vp, i64, i64, i64, i64, i64, vp, vp, i64, vp]),
         'bvq_kth_passes': (i32, [i32]),
         'bvq_kth_hist_offset': (i64, [i32, i64, i32]),
         'bvq_kth_begin': (i32, [i32, i64, i32, i64, dbl, vp, i64, vp]),
@@ -383,6 +384,22 @@ def kth_value(x, k, outer, channels, inner, abs_key):
                                 stream_ptr(dev)), 'bvq_kth_value')
         if _timer is not None:
             _timer.after('bvq_kth_value')
+    return out
+
+
+def kth_pair(x, k_first, k_second, outer, channels, inner, abs_key):
+    """two ranks of the same tensor, one histogram read where the per-tensor route applies -> [2, channels]"""
+    dev = require_device(x)
+    assert x.is_contiguous() and x.numel() == outer * channels * inner
+    dt = dtype_code(x.dtype)
+    out = torch.empty(2, channels, dtype=x.dtype, device=dev)
+    wsb = int(lib.bvq_kth_workspace_bytes(dt, outer, channels, inner))
+    if wsb < 0:
+        raise BvqError('bvq_kth_workspace_bytes: bad arguments')
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with _DeviceGuard(dev):
+        check(lib.bvq_kth_pair(int(abs_key), dt, ptr(x), outer, channels, inner, int(k_first), int(k_second), ptr(out),
+                               ptr(ws), wsb, stream_ptr(dev)), 'bvq_kth_pair')
     return out
 
 

@@ -154,6 +154,30 @@ class _KthValueFn(Function):
         return _unrows(dx, x, dim), None, None, None, None
 
 
+class _KthPairFn(Function):
+    """two ranks of x in one call (nat.kth_pair: one histogram read for a big flat input) -> (k_first-th value,
+    k_second-th value); backward as two _KthValueFn backwards added up"""
+
+    @staticmethod
+    def forward(ctx, x, k_first, k_second, dim):
+        xc, outer, ch, inner, out_shape = _as_rows(x, dim)
+        both = nat.kth_pair(xc.reshape(-1), k_first, k_second, outer, ch, inner, False)
+        ctx.layout = (outer, ch, inner, dim)
+        ctx.save_for_backward(x, both)
+        return both[0].reshape(out_shape), both[1].reshape(out_shape)
+
+    @staticmethod
+    def backward(ctx, g_first, g_second):
+        x, both = ctx.saved_tensors
+        outer, ch, inner, dim = ctx.layout
+        xc, _, _, _, _ = _as_rows(x, dim)
+        flat = xc.reshape(-1)
+        kind = nat.MATCH_VALUE | nat.MATCH_FIRST
+        dx = nat.stat_bwd(kind, flat, both[0].contiguous(), g_first.reshape(-1), outer, ch, inner)
+        dx = nat.stat_bwd(kind, flat, both[1].contiguous(), g_second.reshape(-1), outer, ch, inner, dx=dx)
+        return _unrows(dx, x, dim), None, None, None
+
+
 def _kth(x: Tensor, k: int, dim: Optional[int], abs_key: bool) -> Tensor:
     return _KthValueFn.apply(x, k, dim, abs_key)
 
@@ -228,8 +252,15 @@ class PercentileInterval(torch.nn.Module):
         self.high_q = high_percentile_q
 
     def forward(self, x: Tensor) -> Tensor:
-        low_result = _percentile(self, x, nat.KTH_LOW, self.low_q, False)
-        high_result = _percentile(self, x, nat.KTH_HIGH, self.high_q, False)
+        if getattr(self, 'bvq_shard_group', None) is None:
+            # both ranks from one pass over x (ranks as in _percentile)
+            n = _numel_along(x, self.stats_reduce_dim)
+            k_low = int(math.ceil(.01 * self.low_q * n))
+            k_high = int(math.floor(.01 * self.high_q * n + 0.5))
+            low_result, high_result = _KthPairFn.apply(x, k_low, k_high, self.stats_reduce_dim)
+        else:
+            low_result = _percentile(self, x, nat.KTH_LOW, self.low_q, False)
+            high_result = _percentile(self, x, nat.KTH_HIGH, self.high_q, False)
         return torch.abs(high_result - low_result)
 
 

@@ -289,15 +289,18 @@ __device__ __forceinline__ void low_count(uint32_t key, uint32_t want, int32_t s
 // the same two addresses
 template <typename T, bool ABS, bool NT, bool SMALL>
 __global__ __launch_bounds__(kBlock) void kth_low_kernel(const T* __restrict__ x, int64_t n, int32_t shift,
-                                                        const uint32_t* __restrict__ sel, uint32_t* __restrict__ gh) {
+                                                        const uint32_t* __restrict__ sel, uint32_t* __restrict__ gh,
+                                                        int32_t nk) {
+  // nk (1 or 2) ranks are served by the same read: rank i has its own chosen bin sel[i] and its own counters
   constexpr int VEC = elem<T>::vec;
-  __shared__ uint32_t lh[SMALL ? kBins : 1];
+  __shared__ uint32_t lh[SMALL ? 2 * kBins : 1];
   if constexpr (SMALL) {
-    for (int b = threadIdx.x; b < (1 << shift); b += kBlock) lh[b] = 0;
+    for (int b = threadIdx.x; b < 2 * kBins; b += kBlock) lh[b] = 0;
     __syncthreads();
   }
   uint32_t* ghist = SMALL ? lh : gh;
-  const uint32_t want = sel[0];
+  const int64_t hstride = SMALL ? kBins : ((int64_t)1 << kLowBitsMax);
+  const uint32_t want = sel[0], want2 = nk > 1 ? sel[1] : 0u;
   const uint32_t lowmask = (1u << shift) - 1u;
   const int64_t chunks = n / VEC;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -314,18 +317,26 @@ __global__ __launch_bounds__(kBlock) void kth_low_kernel(const T* __restrict__ x
     for (int j = 0; j < kSelUnroll; ++j) {
       if (ok[j]) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) low_count(sel_key<T, ABS>(xv[j].v[k]), want, shift, lowmask, ghist);
+        for (int k = 0; k < VEC; ++k) {
+          const uint32_t key = sel_key<T, ABS>(xv[j].v[k]);
+          low_count(key, want, shift, lowmask, ghist);
+          if (nk > 1) low_count(key, want2, shift, lowmask, ghist + hstride);
+        }
       }
     }
   }
-  if (blockIdx.x == 0 && chunks * VEC + threadIdx.x < n)
-    low_count(sel_key<T, ABS>(x[chunks * VEC + threadIdx.x]), want, shift, lowmask, ghist);
+  if (blockIdx.x == 0 && chunks * VEC + threadIdx.x < n) {
+    const uint32_t key = sel_key<T, ABS>(x[chunks * VEC + threadIdx.x]);
+    low_count(key, want, shift, lowmask, ghist);
+    if (nk > 1) low_count(key, want2, shift, lowmask, ghist + hstride);
+  }
   if constexpr (SMALL) {
     __syncthreads();
-    for (int b = threadIdx.x; b < (1 << shift); b += kBlock) {
-      const uint32_t c = lh[b];
-      if (c) atomicAdd(&gh[b], c);
-    }
+    for (int i = 0; i < nk; ++i)
+      for (int b = threadIdx.x; b < (1 << shift); b += kBlock) {
+        const uint32_t c = lh[i * kBins + b];
+        if (c) atomicAdd(&gh[(int64_t)i * ((int64_t)1 << kLowBitsMax) + b], c);
+      }
   }
 }
 
@@ -389,7 +400,7 @@ static int64_t sel_steps_bytes(int dtype, int64_t channels) {
 
 // (+ the per-tensor route of bvq_kth_value behind the stepwise layout: 32768 + 2^17 counters, key, rank)
 static int64_t sel_wide_bytes() {
-  return ((int64_t)kBins15 + ((int64_t)1 << kLowBitsMax)) * (int64_t)sizeof(uint32_t) + 64;
+  return ((int64_t)kBins15 + 2 * ((int64_t)1 << kLowBitsMax)) * (int64_t)sizeof(uint32_t) + 64;
 }
 
 static int64_t sel_workspace_bytes(int dtype, int64_t channels) {
@@ -560,6 +571,72 @@ extern "C" int bvq_kth_finish(int abs_key, int dtype, int64_t channels, void* ou
   return check_launch("bvq_kth_finish");
 }
 
+// per-tensor route (see kth_hist15_kernel): nk = 1 or 2 ranks from ONE histogram read (+ one read for the low bits
+// of both); out[nk]
+static bool wide_select_applies(int64_t channels, int64_t n, const void* x) {
+  static const int wide = env_flag("BVQ_KTH_WIDE", 1);
+  return wide && channels == 1 && n >= ((int64_t)1 << 22) && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+
+static int wide_select(int abs_key, int dtype, const void* x, int64_t n, const int64_t* ks, int nk, void* out,
+                       void* workspace, int64_t workspace_bytes, bvq_stream_t stream) {
+  if (workspace_bytes < sel_workspace_bytes(dtype, 1)) {
+    set_error("bvq_kth_value: workspace too small");
+    return BVQ_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* base = reinterpret_cast<char*>(workspace) + (sel_steps_bytes(dtype, 1) + 255) / 256 * 256;
+  uint32_t* hist = reinterpret_cast<uint32_t*>(base);  // [32768]
+  uint32_t* low = hist + kBins15;                      // [2][1 << 17]
+  const int64_t lstride = (int64_t)1 << kLowBitsMax;
+  int64_t* krem = reinterpret_cast<int64_t*>(low + 2 * lstride);  // [2]
+  uint32_t* sel = reinterpret_cast<uint32_t*>(krem + 2);          // [2]
+  const int key_bits = (dtype == BVQ_F32 ? 32 : 16) - (abs_key ? 1 : 0);
+  const int shift = key_bits - 15;  // 0, 1, 16 or 17 low bits left for the second read
+  const int32_t words = kBins15 + (shift ? (int32_t)(2 * lstride) : 0);
+  kth_zero_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(hist, words);
+  const bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
+  // one workgroup per CU is all the LDS allows; 256 of them cover the chip
+#define BVQ_WIDE(T, ABS)                                                                                          \
+  do {                                                                                                            \
+    const T* xp = reinterpret_cast<const T*>(x);                                                                  \
+    if (nt)                                                                                                       \
+      kth_hist15_kernel<T, ABS, true><<<dim3(256), dim3(kBlock15), 0, st>>>(xp, n, shift, hist);                  \
+    else                                                                                                          \
+      kth_hist15_kernel<T, ABS, false><<<dim3(256), dim3(kBlock15), 0, st>>>(xp, n, shift, hist);                 \
+    for (int i = 0; i < nk; ++i)                                                                                  \
+      kth_pick_wide_kernel<<<dim3(1), dim3(kBlock15), 0, st>>>(hist, kBins15, 15, 1, ks[i], sel + i, krem + i);   \
+    if (shift) {                                                                                                  \
+      if (shift <= kDigitBits)                                                                                    \
+        kth_low_kernel<T, ABS, false, true><<<dim3(1024), dim3(kBlock), 0, st>>>(xp, n, shift, sel, low, nk);     \
+      else if (nt)                                                                                                \
+        kth_low_kernel<T, ABS, true, false><<<dim3(2048), dim3(kBlock), 0, st>>>(xp, n, shift, sel, low, nk);     \
+      else                                                                                                        \
+        kth_low_kernel<T, ABS, false, false><<<dim3(2048), dim3(kBlock), 0, st>>>(xp, n, shift, sel, low, nk);    \
+      for (int i = 0; i < nk; ++i)                                                                                \
+        kth_pick_wide_kernel<<<dim3(1), dim3(kBlock15), 0, st>>>(low + i * lstride, 1 << shift, shift, 0, 0,      \
+                                                                 sel + i, krem + i);                              \
+    }                                                                                                             \
+    kth_store_kernel<T, ABS><<<dim3(1), dim3(64), 0, st>>>(sel, out, nk);                                         \
+  } while (0)
+#define BVQ_WIDE_DT(ABS)        \
+  do {                          \
+    if (dtype == BVQ_F32)       \
+      BVQ_WIDE(float, ABS);     \
+    else if (dtype == BVQ_BF16) \
+      BVQ_WIDE(bf16_t, ABS);    \
+    else                        \
+      BVQ_WIDE(f16_t, ABS);     \
+  } while (0)
+  if (abs_key)
+    BVQ_WIDE_DT(true);
+  else
+    BVQ_WIDE_DT(false);
+#undef BVQ_WIDE_DT
+#undef BVQ_WIDE
+  return check_launch("bvq_kth_value/wide");
+}
+
 extern "C" int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t outer, int64_t channels,
                              int64_t inner, int64_t k, void* out, void* workspace,
                              int64_t workspace_bytes, bvq_stream_t stream) {
@@ -576,65 +653,41 @@ extern "C" int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t oute
     set_error("bvq_kth_value: null pointer");
     return BVQ_ERR_INVALID;
   }
-  static const int wide = env_flag("BVQ_KTH_WIDE", 1);
-  if (wide && channels == 1 && per_channel >= ((int64_t)1 << 22) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-    if (workspace_bytes < sel_workspace_bytes(dtype, channels)) {
-      set_error("bvq_kth_value: workspace too small");
-      return BVQ_ERR_WORKSPACE;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    char* base = reinterpret_cast<char*>(workspace) + (sel_steps_bytes(dtype, channels) + 255) / 256 * 256;
-    uint32_t* hist = reinterpret_cast<uint32_t*>(base);                   // [32768]
-    uint32_t* low = hist + kBins15;                                       // [1 << shift]
-    int64_t* krem = reinterpret_cast<int64_t*>(low + ((int64_t)1 << kLowBitsMax));
-    uint32_t* sel = reinterpret_cast<uint32_t*>(krem + 1);
-    const int key_bits = (dtype == BVQ_F32 ? 32 : 16) - (abs_key ? 1 : 0);
-    const int shift = key_bits - 15;  // 0, 1, 16 or 17 low bits left for the second read
-    const int32_t words = kBins15 + (shift ? (1 << shift) : 0);
-    kth_zero_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(hist, words);
-    const bool nt = per_channel * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
-    // one workgroup per CU is all the LDS allows; 256 of them cover the chip
-#define BVQ_WIDE(T, ABS)                                                                                               \
-  do {                                                                                                                 \
-    const T* xp = reinterpret_cast<const T*>(x);                                                                       \
-    if (nt)                                                                                                            \
-      kth_hist15_kernel<T, ABS, true><<<dim3(256), dim3(kBlock15), 0, st>>>(xp, per_channel, shift, hist);            \
-    else                                                                                                               \
-      kth_hist15_kernel<T, ABS, false><<<dim3(256), dim3(kBlock15), 0, st>>>(xp, per_channel, shift, hist);           \
-    kth_pick_wide_kernel<<<dim3(1), dim3(kBlock15), 0, st>>>(hist, kBins15, 15, 1, k, sel, krem);                      \
-    if (shift) {                                                                                                       \
-      if (shift <= kDigitBits)                                                                                         \
-        kth_low_kernel<T, ABS, false, true><<<dim3(1024), dim3(kBlock), 0, st>>>(xp, per_channel, shift, sel, low);   \
-      else if (nt)                                                                                                     \
-        kth_low_kernel<T, ABS, true, false><<<dim3(2048), dim3(kBlock), 0, st>>>(xp, per_channel, shift, sel, low);   \
-      else                                                                                                             \
-        kth_low_kernel<T, ABS, false, false><<<dim3(2048), dim3(kBlock), 0, st>>>(xp, per_channel, shift, sel, low);  \
-      kth_pick_wide_kernel<<<dim3(1), dim3(kBlock15), 0, st>>>(low, 1 << shift, shift, 0, 0, sel, krem);               \
-    }                                                                                                                  \
-    kth_store_kernel<T, ABS><<<dim3(1), dim3(64), 0, st>>>(sel, out, 1);                                               \
-  } while (0)
-#define BVQ_WIDE_DT(ABS)       \
-  do {                         \
-    if (dtype == BVQ_F32)      \
-      BVQ_WIDE(float, ABS);    \
-    else if (dtype == BVQ_BF16) \
-      BVQ_WIDE(bf16_t, ABS);   \
-    else                       \
-      BVQ_WIDE(f16_t, ABS);    \
-  } while (0)
-    if (abs_key)
-      BVQ_WIDE_DT(true);
-    else
-      BVQ_WIDE_DT(false);
-#undef BVQ_WIDE_DT
-#undef BVQ_WIDE
-    return check_launch("bvq_kth_value/wide");
-  }
+  if (wide_select_applies(channels, per_channel, x))
+    return wide_select(abs_key, dtype, x, per_channel, &k, 1, out, workspace, workspace_bytes, stream);
   int rc = bvq_kth_begin(dtype, channels, BVQ_KTH_EXPLICIT, k, 0.0, workspace, workspace_bytes, stream);
   for (int p = 0; !rc && p < passes_for(dtype); ++p) {
     rc = bvq_kth_hist(abs_key, dtype, x, outer, channels, inner, p, workspace, workspace_bytes, stream);
     if (!rc) rc = bvq_kth_pick(dtype, channels, p, BVQ_KTH_EXPLICIT, 0.0, workspace, workspace_bytes, stream);
   }
   if (!rc) rc = bvq_kth_finish(abs_key, dtype, channels, out, workspace, workspace_bytes, stream);
+  return rc;
+}
+
+extern "C" int bvq_kth_pair(int abs_key, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+                            int64_t k_first, int64_t k_second, void* out, void* workspace, int64_t workspace_bytes,
+                            bvq_stream_t stream) {
+  if (dtype < BVQ_F32 || dtype > BVQ_F16 || outer < 0 || channels < 1 || inner < 0) {
+    set_error("bvq_kth_pair: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  const int64_t per_channel = outer * inner;
+  if (k_first < 1 || k_first > per_channel || k_second < 1 || k_second > per_channel) {
+    set_error("bvq_kth_pair: rank out of range [1, %lld]", (long long)per_channel);
+    return BVQ_ERR_INVALID;
+  }
+  if (!x || !out || !workspace) {
+    set_error("bvq_kth_pair: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  if (wide_select_applies(channels, per_channel, x)) {
+    const int64_t ks[2] = {k_first, k_second};
+    return wide_select(abs_key, dtype, x, per_channel, ks, 2, out, workspace, workspace_bytes, stream);
+  }
+  int rc = bvq_kth_value(abs_key, dtype, x, outer, channels, inner, k_first, out, workspace, workspace_bytes, stream);
+  if (!rc)
+    rc = bvq_kth_value(abs_key, dtype, x, outer, channels, inner, k_second,
+                       reinterpret_cast<char*>(out) + channels * (int64_t)dtype_size(dtype), workspace, workspace_bytes,
+                       stream);
   return rc;
 }

@@ -240,6 +240,13 @@ int bvq_abs_affine_bwd(int dtype, const void* x, const float* a, const float* b,
 int64_t bvq_kth_workspace_bytes(int dtype, int64_t outer, int64_t channels, int64_t inner);
 int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
                   int64_t k, void* out, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
+/* Two ranks of the same tensor in one call -- PercentileInterval's low and high percentile
+ * (B/core/stats/stats_op.py:97-126): out[0][channels] = the k_first-th value, out[1][channels] = the k_second-th.
+ * For channels == 1 (>= 4M elements, 16-byte aligned) both come from ONE histogram read (+ one read for the low
+ * key bits of both); otherwise the same as two bvq_kth_value calls.  Workspace: bvq_kth_workspace_bytes. */
+int bvq_kth_pair(int abs_key, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+                 int64_t k_first, int64_t k_second, void* out, void* workspace, int64_t workspace_bytes,
+                 bvq_stream_t stream);
 
 /* The same selection in steps, for a tensor whose batch is sharded over several devices (one process
  * per GPU): every shard histograms its own elements, the caller sums the histogram of the pass over the

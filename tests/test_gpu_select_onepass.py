@@ -60,3 +60,36 @@ def test_wide_kth_value_on_constant_runs(dn):
     c = torch.full((n,), 1.37, device=DEV).to(dt)
     for k in (1, n // 2, n):
         assert nat.kth_value(c, k, 1, 1, n, False).item() == c[0].item()
+
+
+@pytest.mark.parametrize('dn', ['bf16', 'f16', 'f32'])
+@pytest.mark.parametrize('layout', [(1, 1, 6_000_003), (1, 1, 70_000), (40, 16, 900)], ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('abs_key', [False, True], ids=['signed', 'abs'])
+def test_kth_pair_equals_two_selections(dn, layout, abs_key):
+    """bvq_kth_pair (PercentileInterval's two ranks from one histogram read) against two bvq_kth_value calls,
+    including both ranks in the same bin and equal ranks"""
+    from brevitas_amd import _native as nat
+    dt = DT[dn]
+    outer, ch, inner = layout
+    n = outer * inner
+    g = torch.Generator(device=DEV).manual_seed(99 + inner)
+    x = (torch.randn(outer * ch * inner, device=DEV, generator=g) * 2 - 0.5).to(dt)
+    for k1, k2 in ((max(1, int(1e-5 * n)), int(0.99999 * n + 0.5)), (n // 2, n // 2 + 1), (7, 7), (n, 1)):
+        both = nat.kth_pair(x, k1, k2, outer, ch, inner, abs_key)
+        assert torch.equal(both[0], nat.kth_value(x, k1, outer, ch, inner, abs_key)), (k1, k2)
+        assert torch.equal(both[1], nat.kth_value(x, k2, outer, ch, inner, abs_key)), (k1, k2)
+
+
+def test_percentile_interval_module_uses_one_pass_and_matches_torch():
+    from brevitas_amd.core.stats.stats_op import PercentileInterval
+    n = 5_000_000
+    x = (torch.randn(n, device=DEV) * 3 + 1).requires_grad_(True)
+    m = PercentileInterval(low_percentile_q=0.01, high_percentile_q=99.99)
+    out = m(x)
+    k_low, k_high = 500, int(0.9999 * n + 0.5)
+    lo, hi = x.detach().kthvalue(k_low)[0], x.detach().kthvalue(k_high)[0]
+    assert out.item() == (hi - lo).abs().item()
+    out.backward()
+    nz = x.grad.nonzero().reshape(-1)
+    assert nz.numel() == 2 and sorted(x.grad[nz].tolist()) == [-1.0, 1.0]
+    assert x.detach()[x.grad > 0].item() == hi.item() and x.detach()[x.grad < 0].item() == lo.item()
