@@ -9,10 +9,22 @@ scale = max(stat, 1e-10)/128, quantize-dequantize; RescalingIntQuant with Runtim
 training mode) followed by its full autograd backward (clamp mask, scale-gradient
 reduction, deposit on the arg-max elements).  Nothing is skipped or cached between steps.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the batch is sharded, every rank holds
-its own [256,512,56,56] shard (weak scaling), and the only exchange is the all-reduce of the
-per-channel statistic (RCCL, <= 4 KB) in forward and of the scale gradient in backward
-(brevitas_amd.distributed).  value = elements quantized by all ranks / max-over-ranks time.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the batch is sharded over the ranks and the
+only exchanges are the all-reduce of the scale statistic (RCCL, <= 4 KB) in forward and the all-gather of
+the scale-gradient sums in backward (brevitas_amd.distributed).  The judged line is WEAK scaling (every
+rank holds its own [256,512,56,56] shard; value = elements quantized by all ranks / max-over-ranks time);
+the same run also times the STRONG-scaled split SURVEY 8e names (a global [256,512,56,56] cut into
+256/N rows per rank) and reports it under "strong".
+
+Other workloads (--workload): the remaining BASELINE.json configs, same JSON shape --
+  weight_conv_int8    config 2: Int8WeightPerChannelFloat on a [512,512,3,3] conv weight (us per step; eager and
+                      HIP-graph replay)
+  act_per_tensor_bf16 config 3: Int8ActPerTensorFloat (MAX statistic) on [256,512,56,56] bf16
+  qconv_layer3        config 4: ResNet-50 layer3 bottleneck quantizers -- Int8 per-tensor activation
+                      [1024,1024,14,14] bf16 sharded 128 per GPU + the three Int8 per-channel weights, replicated
+  qlinear_8192        config 5: Int4WeightPerChannelFloat on Linear[8192,8192] + Int8ActPerTensorFloat on
+                      [8192,8192] bf16 rows per GPU, per-tensor statistic all-reduced over the ranks
+  weight_linear_int4  config 5's weight alone (eager and HIP-graph replay)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel (the backward) priced in algorithmic HBM bytes per launch over its
@@ -32,15 +44,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# The first ~10 ms of load after an idle GPU run 5-10 % slow (profiles/r02/transient.txt: the step time
+# rises over steps 2..7 and settles by step ~15, with the reported sclk still ramping): steps before the W
+# requested warm-up steps, untimed, until at least this many steps have run.
+SETTLE_STEPS = 40
 
+ACT_SHAPE = (256, 512, 56, 56)
 WORKLOADS = {
-    # name: (shape, dtype, per_channel, description)
-    'act_per_channel_bf16': ((256, 512, 56, 56), torch.bfloat16, True,
+    # name: (kind, dtype, description)
+    'act_per_channel_bf16': ('act_pc', torch.bfloat16,
                              'Int8 per-channel act fake-quant fwd+bwd, AbsMax stats, [256,512,56,56] bf16'),
-    'act_per_tensor_bf16': ((256, 512, 56, 56), torch.bfloat16, False,
+    'act_per_tensor_bf16': ('act_pt', torch.bfloat16,
                             'Int8ActPerTensorFloat(MAX stats) fwd+bwd, [256,512,56,56] bf16'),
-    'act_per_channel_f32': ((256, 512, 56, 56), torch.float32, True,
+    'act_per_channel_f32': ('act_pc', torch.float32,
                             'Int8 per-channel act fake-quant fwd+bwd, AbsMax stats, [256,512,56,56] f32'),
+    'weight_conv_int8': ('weight_conv', torch.float32,
+                         'Int8WeightPerChannelFloat fwd+bwd on a [512,512,3,3] f32 conv weight'),
+    'weight_linear_int4': ('weight_linear', torch.bfloat16,
+                           'Int4WeightPerChannelFloat fwd+bwd on a [8192,8192] bf16 linear weight'),
+    'qconv_layer3': ('qconv', torch.bfloat16,
+                     'ResNet-50 layer3 bottleneck quantizers: Int8ActPerTensorFloat(MAX) on [128,1024,14,14] bf16 per GPU '
+                     '(batch 1024 over 8) + Int8WeightPerChannelFloat on [256,1024,1,1], [256,256,3,3], [1024,256,1,1]'),
+    'qlinear_8192': ('qlinear', torch.bfloat16,
+                     'Linear[8192,8192]: Int4WeightPerChannelFloat (replicated) + Int8ActPerTensorFloat(MAX) on '
+                     '[8192,8192] bf16 activation rows per GPU, statistic all-reduced'),
 }
 
 
@@ -68,6 +95,58 @@ def build_quantizer(channels, per_channel, device, group=None):
     return q
 
 
+class Job:
+    """one workload instance on one rank: step(), the elements a step quantizes, its algorithmic bytes"""
+
+    def __init__(self, kind, dtype, device, group, rank, act_shape=None):
+        import brevitas_amd.quant as Q
+        torch.manual_seed(123456 + rank)
+        self.kind, self.dtype = kind, dtype
+        self.acts, self.weights = [], []   # (x, g, quantizer)
+        b = torch.tensor([], dtype=dtype).element_size()
+        if kind in ('act_pc', 'act_pt'):
+            shape = act_shape or ACT_SHAPE
+            x = torch.randn(shape, device=device, dtype=dtype).requires_grad_(True)
+            g = torch.randn(shape, device=device, dtype=dtype)
+            self.acts.append((x, g, build_quantizer(shape[1], kind == 'act_pc', device, group)))
+        elif kind in ('weight_conv', 'weight_linear'):
+            shape, scale, bits = ((512, 512, 3, 3), 0.02, 8) if kind == 'weight_conv' else ((8192, 8192), 0.01, 4)
+            w = torch.nn.Parameter((torch.randn(shape, device=device) * scale).to(dtype))
+            g = torch.randn(shape, device=device, dtype=dtype)
+            self.weights.append((w, g, Q.Int8WeightPerChannelFloat(w, bit_width=bits).to(device)))
+        elif kind == 'qconv':
+            shape = act_shape or (128, 1024, 14, 14)
+            x = torch.randn(shape, device=device, dtype=dtype).requires_grad_(True)
+            g = torch.randn(shape, device=device, dtype=dtype)
+            self.acts.append((x, g, build_quantizer(shape[1], False, device, group)))
+            torch.manual_seed(123456)  # replicated weights: the same on every rank
+            for ws in ((256, 1024, 1, 1), (256, 256, 3, 3), (1024, 256, 1, 1)):
+                w = torch.nn.Parameter((torch.randn(ws, device=device) * 0.02).to(dtype))
+                self.weights.append((w, torch.randn(ws, device=device, dtype=dtype),
+                                     Q.Int8WeightPerChannelFloat(w).to(device)))
+        elif kind == 'qlinear':
+            shape = act_shape or (8192, 8192)
+            x = torch.randn(shape, device=device, dtype=dtype).requires_grad_(True)
+            g = torch.randn(shape, device=device, dtype=dtype)
+            self.acts.append((x, g, build_quantizer(shape[1], False, device, group)))
+            torch.manual_seed(123456)
+            w = torch.nn.Parameter((torch.randn(8192, 8192, device=device) * 0.01).to(dtype))
+            self.weights.append((w, torch.randn(8192, 8192, device=device, dtype=dtype),
+                                 Q.Int4WeightPerChannelFloat(w).to(device)))
+        else:
+            raise ValueError(kind)
+        self.n_elem = sum(t[0].numel() for t in self.acts + self.weights)
+        self.n_act = sum(t[0].numel() for t in self.acts)
+        self.bytes_per_elem = 6 * b  # stat read + fwd read/write + bwd 2 reads / 1 write (SURVEY 8d)
+        self.elsize = b
+
+    def step(self):
+        for x, g, q in self.acts + self.weights:
+            x.grad = None
+            y = q(x)[0]
+            y.backward(g)
+
+
 class KernelTimer:
     """HIP-event brackets around the named C-ABI calls, on the stream they are launched on"""
 
@@ -92,6 +171,10 @@ class KernelTimer:
         ts = [a.elapsed_time(b) for a, b in self.pairs[name] if b is not None]
         return sum(ts) / len(ts) if ts else None
 
+    def reset(self):
+        for v in self.pairs.values():
+            del v[:]
+
 
 def usable_cpus():
     """host threads this process may really use: affinity mask, capped by the cgroup CPU quota"""
@@ -108,8 +191,6 @@ def usable_cpus():
 
 def cpu_baseline(shape, dtype, per_channel, budget_s=12.0):
     """time the oracle (oracle/, a port of the reference algorithm) on a bounded sample"""
-    import numpy as np
-
     os.environ.setdefault('OMP_NUM_THREADS', str(usable_cpus()))  # before libgomp starts its pool
     import oracle as O
     O.build()
@@ -156,6 +237,58 @@ def cpu_baseline(shape, dtype, per_channel, budget_s=12.0):
                                                       iters, el)}
 
 
+def timed_run(job, steps, warmup, settle, world, device, timer=None, stride=8):
+    """settle + warm-up steps untimed, then `steps` steps between barriers -> max-over-ranks seconds"""
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(settle + warmup):
+        job.step()
+    barrier()
+    # the per-call HIP events are recorded on every `stride`-th step only: each record is a barrier packet
+    # in the queue and costs the GPU ~5 us of idle time (profiles/r01_gap_analysis.txt)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if timer is not None:
+            timer.enabled = i % stride == 0
+        job.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if timer is not None:
+        timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def graph_replay_us(job, iters=200):
+    """the same step captured into a HIP graph (every launch goes to the caller's stream, nothing is read back):
+    us per replay"""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            job.step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        job.step()
+    for _ in range(10):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e6
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -163,6 +296,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--workload', default='act_per_channel_bf16', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-settle', action='store_true',
+                    help='developer option: do not run the untimed clock-settling steps before the warm-up')
     ap.add_argument('--timer-stride', type=int, default=8,
                     help='record the per-call HIP events on every n-th timed step (1: every step)')
     ap.add_argument('--shard-path', action='store_true',
@@ -179,12 +314,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    shape, dtype, per_channel, descr = WORKLOADS[args.workload]
+    kind, dtype, descr = WORKLOADS[args.workload]
     # The CPU baseline runs FIRST, before this process touches the GPU: it may have to (re)build the
     # oracle with `make`, and a GPU-initialised process must not spawn other programs on the box.
     baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        baseline = cpu_baseline(shape, dtype, per_channel)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and kind in ('act_pc', 'act_pt'):
+        baseline = cpu_baseline(ACT_SHAPE, dtype, kind == 'act_pc')
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, args.gpus))
@@ -204,82 +339,104 @@ def main():
         group = dist.group.WORLD
 
     from brevitas_amd import _native as nat
-    torch.manual_seed(123456 + rank)
-    x = torch.randn(shape, device=device, dtype=dtype).requires_grad_(True)
-    g = torch.randn(shape, device=device, dtype=dtype)
-    q = build_quantizer(shape[1], per_channel, device, group)
-    n_elem = x.numel()
-
-    timer = KernelTimer('bvq_fakequant_bwd', 'bvq_fakequant_fwd', 'bvq_stats')
+    job = Job(kind, dtype, device, group, rank)
+    timer = KernelTimer('bvq_fakequant_bwd', 'bvq_fakequant_fwd', 'bvq_stats', 'bvq_stats_fakequant_fwd')
     nat.set_kernel_timer(timer)
+    settle = 0 if args.no_settle else max(0, SETTLE_STEPS - args.warmup)
+    elapsed = timed_run(job, args.steps, args.warmup, settle, world, device, timer, args.timer_stride)
+    nat.set_kernel_timer(None)
 
-    def step():
-        x.grad = None
-        y, scale, zp, bw = q(x)
-        y.backward(g)
+    replay_us = None
+    if world == 1 and kind in ('weight_conv', 'weight_linear'):
+        replay_us = graph_replay_us(job)
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+    # what the report needs of the weak-scaled job (its tensors are freed before the strong-scaled run)
+    class Sizes:
+        n_elem, n_act, elsize, bytes_per_elem = job.n_elem, job.n_act, job.elsize, job.bytes_per_elem
+        shapes = [list(t[0].shape) for t in job.acts + job.weights]
+        bwd_elems = job.acts[0][0].numel() if job.acts else job.weights[0][0].numel()
+        act_shape = tuple(job.acts[0][0].shape) if job.acts else None
+    del job
+    torch.cuda.empty_cache()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # the per-call HIP events are recorded on every `timer_stride`-th step only: each record is a barrier packet
-    # in the queue and costs the GPU ~5 us of idle time (profiles/r01_gap_analysis.txt)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        timer.enabled = i % args.timer_stride == 0
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # strong scaling: the GLOBAL activation of the workload cut into 1/world of its rows per rank
+    strong = None
+    if world > 1 and Sizes.act_shape is not None:
+        full = Sizes.act_shape
+        # the global batch of the workload: the named activation itself, or (config 4) batch 1024
+        rows = {'qconv': 1024}.get(kind, full[0]) // world
+        if rows >= 1:
+            sjob = Job(kind, dtype, device, group, rank, act_shape=(rows,) + full[1:])
+            s_el = timed_run(sjob, args.steps, args.warmup, 0, world, device)
+            # activation rows are split over the ranks; replicated weights are quantized by every rank
+            s_elems = sjob.n_act * world + (sjob.n_elem - sjob.n_act) * world
+            strong = {'value': round(s_elems * args.steps / s_el / 1e9, 3), 'unit': 'Gelem/s',
+                      'ms_per_step': round(s_el / args.steps * 1e3, 4), 'scaling': 'strong',
+                      'global_activation': [rows * world] + list(full[1:]), 'rows_per_gpu': rows}
+            del sjob
+    job = Sizes
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = n_elem * world * args.steps / elapsed / 1e9
-        b = x.element_size()
+        # weights are replicated: every rank quantizes its own copy, counted once per rank (that is the work done)
+        value = job.n_elem * world * args.steps / elapsed / 1e9
+        b = job.elsize
+        headline = kind == 'act_pc'
         # algorithmic bytes of the backward kernel per launch: read g + read x + write dx
-        bwd_bytes = 3 * b * n_elem
+        bwd_elems = job.bwd_elems
+        bwd_bytes = 3 * b * bwd_elems
         bwd_ms = timer.mean_ms('bvq_fakequant_bwd')
         achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh).get(args.workload, {}).get('bvq_fakequant_bwd')
+                tj = json.load(fh)
+            traffic = tj.get(args.workload, {}).get('bvq_fakequant_bwd')
+            if traffic is not None:
+                traffic_src = 'profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier ' \
+                              'run of this command (%s), not measured by this run' % tj.get('_source', 'see profiles/README.md')
+        dt_name = str(dtype).replace('torch.', '').replace('bfloat16', 'bf16').replace('float32', 'f32')
+        metric = 'Gelem/s fused int8 fake-quant fwd+bwd, per-channel, [256,512,56,56]' if headline else \
+            'Gelem/s fake-quant fwd+bwd, ' + args.workload
         out = {
-            'metric': 'Gelem/s fused int8 fake-quant fwd+bwd, per-channel, [256,512,56,56]',
+            'metric': metric,
             'value': round(value, 3), 'unit': 'Gelem/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': str(dtype).replace('torch.', '').replace(
-                'bfloat16', 'bf16').replace('float32', 'f32'),
+            'warmup': args.warmup, 'settle_steps': settle, 'ms_per_step': round(ms_per_step, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dt_name,
             'data': 'synthetic',
-            'config': {'workload': descr, 'name': args.workload, 'shape_per_gpu': list(shape),
-                       'quantizer': 'RescalingIntQuant(IntQuant(int8, TensorClamp), RuntimeStatsScaling(AbsMax), '
-                                    'IntScaling, ZeroZeroPoint, BitWidthConst(8)), training mode',
-                       'parallelism': 'batch-sharded x%d, all-reduce(MAX) of the statistic' % world
-                       if world > 1 else 'single GPU',
-                       'algorithmic_bytes_per_elem': 6 * b},
-            'hbm_frac_whole_step': round(6 * b * n_elem / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            'config': {'workload': descr, 'name': args.workload,
+                       'tensors_per_gpu': job.shapes,
+                       'quantizer': 'RescalingIntQuant(IntQuant, RuntimeStatsScaling(AbsMax) / StatsFromParameterScaling'
+                                    '(AbsMax), IntScaling, ZeroZeroPoint, BitWidthConst), training mode',
+                       'parallelism': ('dp%d: activations batch-sharded over %d RCCL ranks, all-reduce(MAX) of the '
+                                       'statistic + all-gather of the scale-gradient sums; weights replicated'
+                                       % (world, world)) if world > 1 else 'single GPU',
+                       'rccl_ranks': world,
+                       'algorithmic_bytes_per_elem': job.bytes_per_elem},
+            'hbm_frac_whole_step': round(job.bytes_per_elem * job.n_elem / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             'roofline': {'kernel': 'fakequant_bwd_kernel (bvq_fakequant_bwd)', 'bound': 'hbm',
                          'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                         'traffic': traffic, 'algorithmic_bytes_per_launch': bwd_bytes,
+                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'algorithmic_bytes_per_launch': bwd_bytes,
                          'avg_launch_ms': round(bwd_ms, 4) if bwd_ms else None},
         }
-        # the other two streaming calls of the step, same method (each bracket includes its launch-bound helpers)
+        if strong is not None:
+            out['strong'] = strong
+        if replay_us is not None:
+            out['us_per_step_eager'] = round(ms_per_step * 1e3, 2)
+            out['us_per_step_graph_replay'] = round(replay_us, 2)
+        # the streaming calls of the step, same method (each bracket includes its launch-bound helpers); the
+        # one-launch forward (statistic + quantizer) moves the statistic's read through the Infinity Cache
         calls = {}
+        n0 = bwd_elems
         for key, name, passes in (('statistic', 'bvq_stats', 1), ('forward', 'bvq_fakequant_fwd', 2),
+                                  ('statistic+forward', 'bvq_stats_fakequant_fwd', 3),
                                   ('backward', 'bvq_fakequant_bwd', 3)):
             ms = timer.mean_ms(name)
             if ms:
-                calls[key] = {'ms': round(ms, 4), 'algorithmic_GBps': round(passes * b * n_elem / (ms * 1e-3) / 1e9, 1)}
+                calls[key] = {'ms': round(ms, 4), 'algorithmic_GBps': round(passes * b * n0 / (ms * 1e-3) / 1e9, 1)}
         out['calls'] = calls
         if baseline is not None:
             out['cpu_baseline'] = baseline

@@ -27,7 +27,7 @@ MATCH_FIRST = 16  # OR-ed: only the first attaining element, even for a whole-te
 PRE_NONE, PRE_RELU = 0, 1
 CODES_I32, CODES_I8, CODES_U8 = 0, 1, 2
 _CODES_TORCH = {CODES_I32: torch.int32, CODES_I8: torch.int8, CODES_U8: torch.uint8}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -36,7 +36,7 @@ EXPORTS = (
     'bvq_tensor_clamp_bwd', 'bvq_abs_binary_sign_grad_bwd', 'bvq_stats_workspace_bytes', 'bvq_stats',
     'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_scale_from_stat', 'bvq_shard_pack', 'bvq_shard_unpack', 'bvq_abs_moments_workspace_bytes', 'bvq_abs_moments',
     'bvq_abs_affine_bwd', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_pair', 'bvq_kth_passes',
-    'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd', 'bvq_set_fused_max_team',
+    'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd',
     'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd_stats_workspace_bytes', 'bvq_fakequant_bwd_stats', 'bvq_fakequant_bwd')
 
 
@@ -77,7 +77,6 @@ def _load(path=None):
         'bvq_stat_bwd': (i32, [i32, i32, vp, vp, vp, vp, i64, i64, i64, i32, vp, i64, vp]),
         'bvq_fakequant_fwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp]),
         'bvq_stats_fakequant_fwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc), vp, vp]),
-        'bvq_set_fused_max_team': (i32, [i32]),
         'bvq_stats_fakequant_fwd': (i32, [ctypes.POINTER(QuantDesc), vp, dbl, i32, dbl, vp, vp, vp, vp, i64, vp]),
         'bvq_fakequant_bwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
         'bvq_fakequant_bwd_stats_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
@@ -318,11 +317,6 @@ def fakequant_fwd(desc, x, scale, zp, want_codes=False, want_y=True):
     return (y, codes) if want_codes else y
 
 
-def set_fused_max_team(workgroups):
-    """largest team of workgroups per channel the one-launch forward may use (default 1); returns the old value"""
-    return int(lib.bvq_set_fused_max_team(int(workgroups)))
-
-
 def stats_fakequant_fwd(desc, x, min_val, int_threshold, scale_dtype):
     """abs-max statistic, scale and quantize-dequantize in ONE launch (x read once) -> (stat, scale, y), or
     None when the shape is not covered by that kernel (the caller takes the two-call route)"""
@@ -445,11 +439,12 @@ def shard_unpack(gathered, world, channels, rank, per_channel, tie_info):
 
 
 def abs_moments(x, outer, channels, inner):
-    """-> float32 [2 * channels]: sum |x| then sum x^2 per channel of x[outer, channels, inner]"""
+    """-> float32 [3 * channels] of x[outer, channels, inner]: per channel sum d, sum d^2 with d = |x| - p, and the
+    pivot p (include/bvq.h): mean |x| = p + sum d / n, var |x| = (sum d^2 - (sum d)^2 / n) / (n - 1)"""
     dev = require_device(x)
     assert x.is_contiguous() and x.numel() == outer * channels * inner
     dt = dtype_code(x.dtype)
-    sums = torch.empty(2 * channels, dtype=torch.float32, device=dev)
+    sums = torch.empty(3 * channels, dtype=torch.float32, device=dev)
     wsb = int(lib.bvq_abs_moments_workspace_bytes(dt, outer, channels, inner))
     if wsb < 0:
         raise BvqError('bvq_abs_moments_workspace_bytes: bad arguments')
@@ -483,6 +478,7 @@ class KthSelectSteps:
         assert x.is_contiguous() and x.numel() == outer * channels * inner
         self.x, self.layout, self.abs_key = x, (outer, channels, inner), int(abs_key)
         self.rule, self.q, self.k = int(rule), float(q), int(k)
+        self.per_channel = outer * inner if channels > 1 else x.numel()  # elements per channel on THIS shard
         self.dt = dtype_code(x.dtype)
         self.passes = int(lib.bvq_kth_passes(self.dt))
         self.wsb = int(lib.bvq_kth_workspace_bytes(self.dt, outer, channels, inner))

@@ -96,12 +96,15 @@ class IntQuant(torch.nn.Module):
             with torch.no_grad():
                 return self.to_int(scale, zero_point, bit_width, x).to(tdt)
         p, qmin, qmax, round_mode, clamp_ste = fa
-        xc = x.detach().contiguous()
+        # the plan describes x in MEMORY order (a dense channels_last tensor is [N*H*W, C] rows): hand the
+        # kernel the same element order and map the codes back to x's logical layout
+        xc, back = _fused._memory_order(x.detach(), p.channels, p.nhwc)
         sc = scale.detach().reshape(-1).contiguous()
         zc = zero_point.detach().reshape(-1).contiguous()
         desc = _fused.make_desc(p, xc, sc, zc, qmin, qmax, round_mode, clamp_ste, nat.OUT_INT)
         desc.codes_dtype = cdt
-        return nat.fakequant_fwd(desc, xc, sc, zc, want_codes=True, want_y=False)
+        codes = nat.fakequant_fwd(desc, xc, sc, zc, want_codes=True, want_y=False)
+        return codes if back is None else codes.permute(back)
 
     def min_int(self, bit_width):
         return min_int(self.signed, self.narrow_range, bit_width)

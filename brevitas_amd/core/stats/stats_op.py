@@ -12,8 +12,26 @@ import torch
 from torch import Tensor
 from torch.autograd import Function
 
+from brevitas_amd import _aten
 from brevitas_amd import _native as nat
 from brevitas_amd.core._state import TolerantLoad
+
+
+def _on_cpu(x: Tensor, group=None) -> bool:
+    """CPU tensors take the pure-torch route (brevitas_amd._aten: the reference's own op composition)"""
+    if x.is_cuda:
+        return False
+    if group is not None:
+        raise NotImplementedError('batch-sharded statistics run on device tensors only')
+    return True
+
+
+def _abs_max(x: Tensor, dim, group=None) -> Tensor:
+    return _aten.abs_max(x, dim) if _on_cpu(x, group) else _AbsMaxFn.apply(x, dim, group)
+
+
+def _min_max(x: Tensor, dim, group=None):
+    return _aten.min_max(x, dim) if _on_cpu(x, group) else _MinMaxFn.apply(x, dim, group)
 
 
 def _as_rows(x: Tensor, dim: Optional[int]):
@@ -187,6 +205,10 @@ def _percentile(module, x: Tensor, rule: int, q: float, abs_key: bool) -> Tensor
     of the n elements each value is selected from -- all shards' elements if the module is batch-sharded"""
     dim = module.stats_reduce_dim
     group = getattr(module, 'bvq_shard_group', None)
+    if _on_cpu(x, group):
+        if abs_key:
+            return _aten.abs_percentile(x, q, dim)
+        return _aten.high_percentile(x, q, dim) if rule == nat.KTH_HIGH else _aten.low_percentile(x, q, dim)
     if group is not None:
         return _KthValueFn.apply(x, (rule, q), dim, abs_key, group)
     n = _numel_along(x, dim)
@@ -252,7 +274,7 @@ class PercentileInterval(torch.nn.Module):
         self.high_q = high_percentile_q
 
     def forward(self, x: Tensor) -> Tensor:
-        if getattr(self, 'bvq_shard_group', None) is None:
+        if getattr(self, 'bvq_shard_group', None) is None and x.is_cuda:
             # both ranks from one pass over x (ranks as in _percentile)
             n = _numel_along(x, self.stats_reduce_dim)
             k_low = int(math.ceil(.01 * self.low_q * n))
@@ -275,7 +297,7 @@ class NegativeMinOrZero(torch.nn.Module):
         self.stats_reduce_dim = stats_reduce_dim
 
     def forward(self, x: Tensor) -> Tensor:
-        _, min_val = _MinMaxFn.apply(x, self.stats_reduce_dim, getattr(self, 'bvq_shard_group', None))
+        _, min_val = _min_max(x, self.stats_reduce_dim, getattr(self, 'bvq_shard_group', None))
         zero = torch.zeros((), dtype=min_val.dtype, device=min_val.device)
         return torch.where(min_val <= zero, min_val, zero)
 
@@ -290,7 +312,7 @@ class AbsMax(torch.nn.Module):
         self.stats_reduce_dim = stats_reduce_dim
 
     def forward(self, x: Tensor):
-        return _AbsMaxFn.apply(x, self.stats_reduce_dim, getattr(self, 'bvq_shard_group', None))
+        return _abs_max(x, self.stats_reduce_dim, getattr(self, 'bvq_shard_group', None))
 
 
 class AbsMinMax(torch.nn.Module):
@@ -303,7 +325,7 @@ class AbsMinMax(torch.nn.Module):
         self.stats_reduce_dim = stats_reduce_dim
 
     def forward(self, x: Tensor):
-        max_val, min_val = _MinMaxFn.apply(x, self.stats_reduce_dim, getattr(self, 'bvq_shard_group', None))
+        max_val, min_val = _min_max(x, self.stats_reduce_dim, getattr(self, 'bvq_shard_group', None))
         return torch.abs(max_val - min_val)
 
 
@@ -318,7 +340,7 @@ class AbsMaxAve(torch.nn.Module):
         self.stats_reduce_dim = stats_reduce_dim
 
     def forward(self, x: Tensor):
-        return torch.mean(_AbsMaxFn.apply(x, self.stats_reduce_dim, getattr(self, 'bvq_shard_group', None)))
+        return torch.mean(_abs_max(x, self.stats_reduce_dim, getattr(self, 'bvq_shard_group', None)))
 
 
 class AbsMaxL2(torch.nn.Module):
@@ -331,7 +353,7 @@ class AbsMaxL2(torch.nn.Module):
         self.stats_reduce_dim = stats_reduce_dim
 
     def forward(self, x: torch.Tensor):
-        per_channel_max = _AbsMaxFn.apply(x, self.stats_reduce_dim, getattr(self, 'bvq_shard_group', None))
+        per_channel_max = _abs_max(x, self.stats_reduce_dim, getattr(self, 'bvq_shard_group', None))
         out = torch.norm(per_channel_max, p=2)
         return out / math.sqrt(per_channel_max.view(-1).shape[0])
 
@@ -345,9 +367,12 @@ class _AbsMomentsFn(Function):
     def forward(ctx, x, dim):
         xc, outer, ch, inner, out_shape = _as_rows(x, dim)
         n = outer * inner
+        # sums of d = |x| - pivot (the channel's first |x|): shifted, so the variance keeps its digits when the
+        # mean is far larger than the spread (torch.var is two-pass / Welford)
         sums = nat.abs_moments(xc.reshape(-1), outer, ch, inner).double()
-        mean = sums[:ch] / n
-        var = (sums[ch:] - sums[:ch] * mean) / (n - 1) if n > 1 else torch.full_like(mean, float('nan'))
+        d1, d2, pivot = sums[:ch], sums[ch:2 * ch], sums[2 * ch:]
+        mean = pivot + d1 / n
+        var = (d2 - d1 * (d1 / n)) / (n - 1) if n > 1 else torch.full_like(mean, float('nan'))
         var = var.clamp_min(0.0)  # rounding of the two sums can leave a tiny negative difference
         ctx.layout = (outer, ch, inner, dim, n)
         ctx.save_for_backward(x, mean)
@@ -367,6 +392,10 @@ class _AbsMomentsFn(Function):
         return _unrows(dx, x, dim), None
 
 
+def _abs_moments(x: Tensor, dim):
+    return _aten.abs_mean_var(x, dim) if _on_cpu(x) else _AbsMomentsFn.apply(x, dim)
+
+
 class AbsAve(torch.nn.Module):
     """mean(|x|) over the whole input or along `stats_reduce_dim` (B/core/stats/stats_op.py:186-199)"""
     bvq_is_stat = True
@@ -376,7 +405,7 @@ class AbsAve(torch.nn.Module):
         self.stats_reduce_dim = stats_reduce_dim
 
     def forward(self, x: Tensor):
-        return _AbsMomentsFn.apply(x, self.stats_reduce_dim)[0]
+        return _abs_moments(x, self.stats_reduce_dim)[0]
 
 
 DEFAULT_STD_DEV_EPSILON = 1e-8
@@ -391,7 +420,7 @@ class _MeanSigmaStdImpl(torch.nn.Module):
         self.epsilon = std_dev_epsilon
 
     def forward(self, x: Tensor, sigma: Tensor):
-        mean_val, var_val = _AbsMomentsFn.apply(x, self.stats_reduce_dim)
+        mean_val, var_val = _abs_moments(x, self.stats_reduce_dim)
         std_val = torch.sqrt(var_val + self.epsilon)
         if self.stats_reduce_dim is not None:
             mean_val = mean_val.view(-1)

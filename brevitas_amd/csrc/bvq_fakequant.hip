@@ -39,11 +39,11 @@ struct QuantArgs {
 #ifndef BVQ_FWD_UNROLL
 #define BVQ_FWD_UNROLL 8
 #endif
-#ifndef BVQ_BWD_UNROLL
-#define BVQ_BWD_UNROLL 2
+#ifndef BVQ_BWD_DEPTH
+#define BVQ_BWD_DEPTH 2
 #endif
-constexpr int kUnroll = BVQ_FWD_UNROLL;     // forward: 16-byte loads of x in flight per lane before arithmetic
-constexpr int kBwdUnroll = BVQ_BWD_UNROLL;  // backward: the same for each of its two input streams (x, g)
+constexpr int kUnroll = BVQ_FWD_UNROLL;   // forward: 16-byte loads of x in flight per lane before arithmetic
+constexpr int kBwdDepth = BVQ_BWD_DEPTH;  // backward: chunks of each input stream (x, g) prefetched ahead of the arithmetic
 
 template <typename CT>
 __device__ __forceinline__ void load_scale_zp(const QuantArgs& a, int32_t channel, float& s, float& z) {
@@ -290,7 +290,8 @@ __device__ __forceinline__ void store_codes(void* base, int codes_dtype, int64_t
   }
 }
 
-template <typename XT, typename CT, int VEC, int RM, bool NT, bool ZP0, bool PRE, typename Div>
+// NT: cache policy of the stores of y; NTL: of the loads of x (the same unless stated)
+template <typename XT, typename CT, int VEC, int RM, bool NT, bool ZP0, bool PRE, bool NTL = NT, typename Div>
 __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, const Div& div, float s,
                                          float z, float qmin, float qmax) {
   const int lane = threadIdx.x & 63;
@@ -311,7 +312,7 @@ __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, cons
     for (int j = 0; j < kUnroll; ++j) {
       ok[j] = cur.valid();
       off[j] = cur.offset(u.row_stride, VEC);
-      xv[j] = load_vec<XT, VEC, NT>(xp + (ok[j] ? off[j] : 0));  // past the end: re-read the unit's first chunk
+      xv[j] = load_vec<XT, VEC, NTL>(xp + (ok[j] ? off[j] : 0));  // past the end: re-read the unit's first chunk
       cur.next();
     }
 #pragma unroll
@@ -467,43 +468,64 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_cols_kernel(ColsQuantArg
 }
 
 // ------------------------------------------------------------------------------------------------
-// statistic + quantizer in ONE kernel: the channel stays in registers between the two
+// statistic + quantizer in ONE kernel, small channels: the channel stays in registers between the two
 // ------------------------------------------------------------------------------------------------
 // AbsMax -> clamp_min -> / int_threshold -> IntQuant (zero zero-point): the stats-scaled graphs of
-// SURVEY 8a.  The two-kernel form reads x twice (statistic, then quantize).  Here a TEAM of
-// workgroups owns one channel at a time: every wave loads one slice of the channel (<= 8 chunks of
-// 16 bytes per lane: 8 KiB per wave) into registers, the team agrees on the channel's maximum through
-// two agent-scope atomics (max, arrival counter), and every wave quantizes what it still holds.
-// x is read ONCE: 2 instead of 3 tensor passes for the forward.
-//
-// Residency: the arrival wait needs all workgroups of a team on the chip at once.  The grid is a
-// whole number of teams and at most 2 workgroups of 512 threads per CU -- well inside what the
-// hardware admits for this kernel (MI355X_MICROARCH.md, Residency) -- and teams are consecutive block
-// ids, which are dispatched together.  As a last resort the wait is bounded: a team that does not
-// assemble within ~2 s poisons its channel with NaN and raises the error word instead of hanging.
+// SURVEY 8a.  The two-kernel form reads x twice (statistic, then quantize).  Here ONE workgroup owns a
+// channel at a time: every wave loads one slice of the channel (<= 8 chunks of 16 bytes per lane: 8 KiB
+// per wave) into registers, the workgroup agrees on the channel's maximum through LDS, and every wave
+// quantizes what it still holds.  x is read ONCE, one launch instead of three.  Channels that do not fit
+// one workgroup's registers take the pipelined kernel below or the two-kernel route.
 constexpr int kFusedSlots = 8;          // 16-byte chunks per lane held in registers
 constexpr int kFusedSliceChunks = 512;  // kWave * kFusedSlots
 constexpr int kFusedMaxWaves = 8;       // waves per workgroup
-constexpr int kFusedSpinLimit = 1 << 20;
 
 struct FusedArgs {
   const void* x;
   void* y;
   void* stat_out;   // [channels], dtype of x
   void* scale_out;  // [channels], scale_dtype
-  uint32_t* stat_bits;  // workspace, zeroed: per-channel running maximum of the |x| keys
-  uint32_t* arrive;     // workspace, zeroed: per-channel arrival counter
-  uint32_t* error;      // workspace, zeroed: set when a team did not assemble
   int64_t outer, inner;
   int32_t channels;
   int32_t cpr;      // chunks per row
   int32_t spr;      // slices per row
   int32_t slices;   // slices per channel = outer * spr
-  int32_t team;     // workgroups per channel
-  int32_t nteams;
   float qmin, qmax, min_val, int_threshold;
   int32_t use_min, scale_dtype, scale_pc, scalar_cast, round_mode, pre_relu;
 };
+
+// statistic (an |x| key) -> the statistic as a float and the scale, with the rounding points of
+// clamp_min_ste(stat, min_val) / int_threshold (ScaleEpilogue of bvq_stats.hip)
+template <typename T>
+__device__ __forceinline__ float scale_from_key(uint32_t key, bool use_min, float min_val, float int_threshold,
+                                                int scale_dtype, float& stat) {
+  if constexpr (elem<T>::id == BVQ_F16)
+    stat = (float)__builtin_bit_cast(f16_t, (uint16_t)key);
+  else
+    stat = __builtin_bit_cast(float, key);
+  const float thr = (use_min && stat < min_val) ? min_val : stat;  // NaN passes, like torch.clamp_min
+  float s = thr / int_threshold;
+  // rounded to the scale's dtype as a tensor op would
+  if (scale_dtype == BVQ_BF16)
+    s = rnd<bf16_t>(s);
+  else if (scale_dtype == BVQ_F16)
+    s = rnd<f16_t>(s);
+  return s;
+}
+template <typename T>
+__device__ __forceinline__ void store_stat_scale(void* stat_out, void* scale_out, int scale_dtype, int32_t c,
+                                                 float stat, float s) {
+  if constexpr (elem<T>::id == BVQ_F32)
+    reinterpret_cast<float*>(stat_out)[c] = stat;
+  else
+    reinterpret_cast<T*>(stat_out)[c] = (T)stat;  // exact: stat is a value of T
+  if (scale_dtype == BVQ_F32)
+    reinterpret_cast<float*>(scale_out)[c] = s;
+  else if (scale_dtype == BVQ_BF16)
+    reinterpret_cast<bf16_t*>(scale_out)[c] = (bf16_t)s;
+  else
+    reinterpret_cast<f16_t*>(scale_out)[c] = (f16_t)s;
+}
 
 template <typename T, int RM, bool PRE, typename Div>
 __device__ __forceinline__ void fused_quantize(const vec_t<T, elem<T>::vec> (&xv)[kFusedSlots], const bool (&ok)[kFusedSlots],
@@ -541,9 +563,7 @@ __global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nwaves = (int)(blockDim.x >> 6);
-  const int team = blockIdx.x / a.team;
-  const int member = blockIdx.x - team * a.team;
-  const int q = member * nwaves + wave;  // this wave's slice of every channel the team visits
+  const int q = wave;  // this wave's slice of every channel the workgroup visits
   const bool active = q < a.slices;
   const int r = active ? q / a.spr : 0;
   const int sl = active ? q - r * a.spr : 0;
@@ -555,7 +575,7 @@ __global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant
   for (int j = 0; j < kFusedSlots; ++j) ok[j] = lane + kWave * j < nch;
   const float qmin = rnd<T>(a.qmin), qmax = rnd<T>(a.qmax);
 
-  for (int32_t c = team; c < a.channels; c += a.nteams) {
+  for (int32_t c = blockIdx.x; c < a.channels; c += gridDim.x) {
     const int64_t base = ((int64_t)r * a.channels + c) * a.inner + (int64_t)sl * kFusedSliceChunks * VEC;
     const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + base;
     T* __restrict__ yp = reinterpret_cast<T*>(a.y) + base;
@@ -581,58 +601,13 @@ __global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant
     if (threadIdx.x == 0) {
       uint32_t bm = 0;
       for (int w = 0; w < nwaves; ++w) bm = sh_max[w] > bm ? sh_max[w] : bm;
-      if (a.team == 1) {  // the workgroup holds the whole channel: no hand-off, no workspace
-        sh_stat = bm;
-      } else {
-      // the team's agreement: max, then arrive; then wait for everybody (agent-scope atomics both sides)
-      __hip_atomic_fetch_max(&a.stat_bits[c], bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(&a.arrive[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int spins = 0;
-      bool timed_out = false;
-      while (__hip_atomic_load(&a.arrive[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)a.team) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > kFusedSpinLimit) {
-          timed_out = true;
-          break;
-        }
-      }
-      uint32_t st = __hip_atomic_load(&a.stat_bits[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (timed_out) {
-        __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        st = elem<T>::id == BVQ_F16 ? 0x7e00u : 0x7fc00000u;  // NaN key: the channel's outputs become NaN
-      }
-      sh_stat = st;
-      }
+      sh_stat = bm;
     }
     __syncthreads();
-    // statistic -> scale (ScaleEpilogue of bvq_stats.hip: same rounding points)
-    const uint32_t sb = sh_stat;
     float stat;
-    if constexpr (elem<T>::id == BVQ_F16)
-      stat = (float)__builtin_bit_cast(f16_t, (uint16_t)sb);
-    else
-      stat = __builtin_bit_cast(float, sb);
-    const float thr = (a.use_min && stat < a.min_val) ? a.min_val : stat;
-    float s = thr / a.int_threshold;
-    // rounded to the scale's dtype as a tensor op would; a 0-dim float32 scale next to a 16-bit tensor is
-    // rounded again by the device's scalar semantics (bvq_scalar_mode)
-    if (a.scale_dtype == BVQ_BF16)
-      s = rnd<bf16_t>(s);
-    else if (a.scale_dtype == BVQ_F16)
-      s = rnd<f16_t>(s);
-    if (member == 0 && threadIdx.x == 0) {
-      if constexpr (elem<T>::id == BVQ_F32)
-        reinterpret_cast<float*>(a.stat_out)[c] = stat;
-      else
-        reinterpret_cast<T*>(a.stat_out)[c] = (T)stat;  // exact: stat is a value of T
-      if (a.scale_dtype == BVQ_F32)
-        reinterpret_cast<float*>(a.scale_out)[c] = s;
-      else if (a.scale_dtype == BVQ_BF16)
-        reinterpret_cast<bf16_t*>(a.scale_out)[c] = (bf16_t)s;
-      else
-        reinterpret_cast<f16_t*>(a.scale_out)[c] = (f16_t)s;
-    }
+    float s = scale_from_key<T>(sh_stat, a.use_min, a.min_val, a.int_threshold, a.scale_dtype, stat);
+    if (threadIdx.x == 0) store_stat_scale<T>(a.stat_out, a.scale_out, a.scale_dtype, c, stat, s);
+    // a 0-dim float32 scale next to a 16-bit tensor is rounded again by the device's scalar semantics
     if (a.scalar_cast && !a.scale_pc) s = rnd<T>(s);
     // phase 2: quantize what the registers still hold
     const int mode = a.round_mode;
@@ -652,6 +627,183 @@ __global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant
     else
       fused_quantize<T, RM, false>(xv, ok, yp, lane, div, s, qmin, qmax, mode);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// statistic + quantizer in ONE launch, large per-channel tensors: a slab pipeline through the Infinity Cache
+// ------------------------------------------------------------------------------------------------
+// A [N,C,H,W] activation far larger than the 256 MiB Infinity Cache (MALL) costs the two-kernel forward three
+// HBM passes: the statistic reads x, the quantizer reads it again and writes y.  A channel's statistic
+// depends on that channel alone, so the tensor is cut into SLABS of `cps` consecutive channels (a few MB to
+// a few tens of MB) and ONE grid walks them as a software pipeline: the workgroups of "phase" p hold the
+// statistic units (S) of slab p interleaved with the quantizer units (Q) of slab p - lag.  Workgroups are
+// dispatched in index order, so while slab p streams in from HBM, slab p - lag -- whose statistic finished
+// long ago, and whose bytes still sit in the Infinity Cache -- is quantized: its second read of x is served
+// on-die, and HBM sees one read of x and one write of y.
+//
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility; agent-scope atomics both sides): an S wave folds
+// its maximum into stat_bits[channel] (atomic max), waits for it (s_waitcnt vmcnt(0)) and adds 1 to its
+// slab's arrival counter (sharded over kPipeShards words); a Q wave polls the counters of ITS slab (relaxed
+// agent-scope loads), then reads the channel's key.  A Q wave waits only for S units that were dispatched
+// `lag` phases earlier and never wait themselves, so the wait is short by construction; it does not DEPEND on
+// the dispatch order either: after kPipeSpinLimit polls a Q wave computes its channel's statistic itself
+// from x (slow, correct), so the kernel finishes under any placement, order or residency.
+constexpr int kPipeShards = 16;
+constexpr int kPipeSpinLimit = 4096;
+
+struct PipeArgs {
+  QuantArgs q;          // x, y, qmin/qmax, round_mode, pre_relu (t / scale / zp unused)
+  void* stat_out;       // [channels], dtype of x
+  void* scale_out;      // [channels], scale_dtype
+  uint32_t* stat_bits;  // workspace, zeroed: per-channel running maximum of the |x| keys
+  uint32_t* done;       // workspace, zeroed: [nslab][kPipeShards] finished S units
+  int64_t outer, inner;
+  int32_t channels, cps, nslab, lag;
+  int32_t rpu_s, nob_s;  // rows (outer indices) per S unit, S units per channel
+  int32_t rpu_q, nob_q;  // the same for Q units
+  int32_t bs, bq;        // workgroups per slab of each kind
+  float min_val, int_threshold;
+  int32_t use_min;
+  int32_t spin_limit;    // polls before a Q wave computes the statistic itself (< 0: at once; test hook)
+};
+
+// max |x| key over a unit (the loop of absmax_kernel, bvq_stats.hip)
+template <typename T, int VEC, bool NT, bool RELU>
+__device__ __forceinline__ uint32_t absmax_unit(const T* __restrict__ xp, const Unit& u, int lane) {
+  constexpr int kU = 8;
+  uint32_t m = 0;
+  ChunkWalker cur;
+  cur.init(u, VEC, lane);
+  const int64_t total = (int64_t)u.nrows * cur.cpr;
+  for (int64_t done = 0; done < total; done += (int64_t)kWave * kU) {
+    vec_t<T, VEC> xv[kU];
+    bool ok[kU];
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      ok[j] = cur.valid();
+      if (ok[j]) xv[j] = load_vec<T, VEC, NT>(xp + cur.offset(u.row_stride, VEC));
+      cur.next();
+    }
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      if (ok[j]) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const uint32_t b = pre_abs_bits<T, RELU>(xv[j].v[k]);
+          m = b > m ? b : m;
+        }
+      }
+    }
+  }
+  return wave_max_u32(m);
+}
+
+template <typename T, int RM, bool SNT, bool QNTL, bool QNTS>
+__global__ __launch_bounds__(kBlock) void pipe_absmax_fakequant_kernel(PipeArgs a) {
+  constexpr int VEC = elem<T>::vec;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int32_t per_phase = a.bs + a.bq;
+  const int32_t phase = (int32_t)(blockIdx.x / (uint32_t)per_phase);
+  const int32_t r = (int32_t)(blockIdx.x - (uint32_t)phase * (uint32_t)per_phase);
+  // the bs S workgroups of a phase are spread evenly among its bq Q workgroups (position rr is an S workgroup
+  // when floor(rr bs / per_phase) steps there); the pattern is rotated from phase to phase so that an integer
+  // spacing does not pin the S workgroups to the same XCDs (workgroup b runs on XCD b % 8)
+  const int32_t rr = (int32_t)(((int64_t)r + 3 * (int64_t)phase) % per_phase);
+  const int32_t sb = (int32_t)(((int64_t)rr * a.bs) / per_phase);
+  const bool is_s = (int32_t)(((int64_t)(rr + 1) * a.bs) / per_phase) > sb;
+  const int32_t idx = is_s ? sb : rr - sb;
+  const int32_t slab = is_s ? phase : phase - a.lag;
+  if (slab < 0 || slab >= a.nslab) return;
+  const int32_t c0 = slab * a.cps;
+  const int32_t cnt = a.channels - c0 < a.cps ? a.channels - c0 : a.cps;  // channels of this slab
+  const int32_t unit = idx * kWavesPerBlock + wave;
+  const T* __restrict__ xbase = reinterpret_cast<const T*>(a.q.x);
+  Unit u;
+  u.valid = true;
+  u.row_stride = (int64_t)a.channels * a.inner;
+  u.len = a.inner;
+  u.id = 0;
+
+  if (is_s) {
+    if (unit >= a.nob_s * cnt) return;
+    const int32_t ob = unit / cnt, cl = unit - ob * cnt;  // channel fastest: neighbouring waves, neighbouring memory
+    const int64_t o0 = (int64_t)ob * a.rpu_s;
+    u.channel = c0 + cl;
+    u.nrows = (int32_t)(a.outer - o0 < a.rpu_s ? a.outer - o0 : a.rpu_s);
+    u.base = (o0 * a.channels + u.channel) * a.inner;
+    u.pos0 = o0 * a.inner;
+    const uint32_t m = a.q.pre_relu ? absmax_unit<T, VEC, SNT, true>(xbase + u.base, u, lane)
+                                    : absmax_unit<T, VEC, SNT, false>(xbase + u.base, u, lane);
+    if (lane == 0) {
+      // a RETURNING atomic: its old value comes back only once the maximum is in place, so the arrival
+      // below cannot overtake it
+      const uint32_t old = __hip_atomic_fetch_max(&a.stat_bits[u.channel], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
+      __hip_atomic_fetch_add(&a.done[slab * kPipeShards + (int)(blockIdx.x % kPipeShards)], 1u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+
+  if (unit >= a.nob_q * cnt) return;
+  const int32_t ob = unit / cnt, cl = unit - ob * cnt;
+  const int64_t o0 = (int64_t)ob * a.rpu_q;
+  u.channel = c0 + cl;
+  u.nrows = (int32_t)(a.outer - o0 < a.rpu_q ? a.outer - o0 : a.rpu_q);
+  u.base = (o0 * a.channels + u.channel) * a.inner;
+  u.pos0 = o0 * a.inner;
+  // wait until every S unit of the slab has arrived
+  const uint32_t expected = (uint32_t)(a.nob_s * cnt);
+  uint32_t key;
+  {
+    int spins = 0;
+    bool ready = false;
+    while (a.spin_limit >= 0) {
+      uint32_t v = lane < kPipeShards
+                       ? __hip_atomic_load(&a.done[slab * kPipeShards + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : 0u;
+#pragma unroll
+      for (int off = kPipeShards / 2; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, kWave);
+      ready = __builtin_amdgcn_readfirstlane((int)v) == (int)expected;
+      if (ready || ++spins > a.spin_limit) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
+    if (ready) {
+      key = __hip_atomic_load(&a.stat_bits[u.channel], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      // never observed; keeps the kernel independent of dispatch order and residency: the channel's
+      // statistic from x itself
+      Unit w = u;
+      w.nrows = (int32_t)a.outer;
+      w.base = (int64_t)u.channel * a.inner;
+      key = a.q.pre_relu ? absmax_unit<T, VEC, false, true>(xbase + w.base, w, lane)
+                         : absmax_unit<T, VEC, false, false>(xbase + w.base, w, lane);
+    }
+    key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+  }
+  float stat;
+  const float s = scale_from_key<T>(key, a.use_min, a.min_val, a.int_threshold, a.q.scale_dtype, stat);
+  if (ob == 0 && lane == 0) store_stat_scale<T>(a.stat_out, a.scale_out, a.q.scale_dtype, u.channel, stat, s);
+  const float qmin = rnd<T>(a.q.qmin), qmax = rnd<T>(a.q.qmax);
+  constexpr bool ZP0 = sizeof(T) == 2;
+#define BVQ_PIPE_UNIT(PRE, DIV) fwd_unit<T, T, VEC, RM, QNTS, ZP0, PRE, QNTL>(a.q, u, DIV, s, 0.f, qmin, qmax)
+  if constexpr (elem<T>::id == BVQ_BF16) {
+    if (bf16_scale_ok(s)) {
+      const DivBf16 div{1.0f / s};
+      if (a.q.pre_relu)
+        BVQ_PIPE_UNIT(true, div);
+      else
+        BVQ_PIPE_UNIT(false, div);
+      return;
+    }
+  }
+  const DivExact div{s};
+  if (a.q.pre_relu)
+    BVQ_PIPE_UNIT(true, div);
+  else
+    BVQ_PIPE_UNIT(false, div);
+#undef BVQ_PIPE_UNIT
 }
 
 #endif  // forward part
@@ -744,34 +896,56 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
   uint32_t umax = 0;  // kBwdDsTies: largest |x| key this lane has seen in the unit's full chunks
   unsigned long long tie_first = ~0ull;
   f2 ds_acc2 = splat2(0.f), dzp_acc2 = splat2(0.f);  // pairwise path; folded into the scalars at the end
-  constexpr int kU = kBwdUnroll;  // chunks per lane in flight, for each of the two input streams
+  // Software-pipelined walk: the loads of chunk i + kD are issued BEFORE chunk i is worked on, so every wave
+  // keeps kD chunks of x and of g in flight while it computes (the counters of the round-1 kernel showed its
+  // waves 45 % of their time in arithmetic or waiting to issue with nothing in flight:
+  // profiles/r02/pmc_backward.md).  One chunk per step, so a 56x56 row (392 chunks) costs 7 steps of
+  // arithmetic instead of 4 x 2.
+  constexpr int kD = kBwdDepth;
   ChunkCursor cur;
   cur.init(u, VEC, lane);
   const int64_t total = (int64_t)u.nrows * cur.cpr;
-  for (int64_t done = 0; done < total; done += (int64_t)kWave * kU) {
-    vec_t<XT, VEC> xv[kU];
-    vec_t<CT, VEC> gv[kU];
-    int64_t off[kU];
-    bool ok[kU];
+  const int32_t steps = (int32_t)((total + kWave - 1) / kWave);  // chunks per lane, the last possibly partial
+  vec_t<XT, VEC> xb[kD];
+  vec_t<CT, VEC> gb[kD];
+  int64_t offb[kD];
+  bool okb[kD];
 #pragma unroll
-    for (int j = 0; j < kU; ++j) {
-      ok[j] = cur.valid();
-      off[j] = cur.offset(u.row_stride, VEC);
-      const int64_t lo = ok[j] ? off[j] : 0;  // past the end: re-read the unit's first chunk
-      xv[j] = load_vec<XT, VEC, NT>(xp + lo);
-      gv[j] = load_vec<CT, VEC, NT>(gp + lo);
-      cur.next();
+  for (int j = 0; j < kD; ++j) {
+    okb[j] = cur.valid();
+    offb[j] = cur.offset(u.row_stride, VEC);
+    if (j < steps) {  // wave-uniform
+      const int64_t lo = okb[j] ? offb[j] : 0;  // past the end: re-read the unit's first chunk
+      xb[j] = load_vec<XT, VEC, NT>(xp + lo);
+      gb[j] = load_vec<CT, VEC, NT>(gp + lo);
     }
+    cur.next();
+  }
+  for (int32_t base = 0; base < steps; base += kD) {
 #pragma unroll
-    for (int j = 0; j < kU; ++j) {
-      if (ok[j]) {
+    for (int j = 0; j < kD; ++j) {
+      if (base + j >= steps) break;  // wave-uniform
+      const vec_t<XT, VEC> xv = xb[j];
+      const vec_t<CT, VEC> gv = gb[j];
+      const int64_t off = offb[j];
+      const bool ok = okb[j];
+      // refill this slot with chunk base + j + kD
+      okb[j] = cur.valid();
+      offb[j] = cur.offset(u.row_stride, VEC);
+      if (base + j + kD < steps) {
+        const int64_t lo = okb[j] ? offb[j] : 0;
+        xb[j] = load_vec<XT, VEC, NT>(xp + lo);
+        gb[j] = load_vec<CT, VEC, NT>(gp + lo);
+      }
+      cur.next();
+      if (ok) {
         vec_t<XT, VEC> dv;
         if constexpr (VEC % 2 == 0) {
 #pragma unroll
           for (int k = 0; k < VEC; k += 2) {
-            const f2 xraw = widen2<XT>(xv[j].v[k], xv[j].v[k + 1]);
+            const f2 xraw = widen2<XT>(xv.v[k], xv.v[k + 1]);
             constexpr bool kSame16 = sizeof(CT) == 2 && sizeof(XT) == 2;  // then XT is CT (dispatch pairs)
-            f2 d = bwd_elem2<CT, RM, MODE, ZP0, kSame16>(PRE ? relu2(xraw) : xraw, widen2<CT>(gv[j].v[k], gv[j].v[k + 1]),
+            f2 d = bwd_elem2<CT, RM, MODE, ZP0, kSame16>(PRE ? relu2(xraw) : xraw, widen2<CT>(gv.v[k], gv.v[k + 1]),
                                                 div, s, z, qmin, qmax, clamp_ste, mode, ds_acc2, dzp_acc2);
             if constexpr (PRE) d = xraw > splat2(0.f) ? d : splat2(0.f);  // torch.relu backward: grad * (x > 0)
             pack2<XT>(d, dv.v[k], dv.v[k + 1]);
@@ -779,8 +953,8 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
         } else {
 #pragma unroll
           for (int k = 0; k < VEC; ++k) {
-            const float xraw = to_f<XT>(xv[j].v[k]);
-            float d = bwd_elem<CT, RM, MODE, ZP0>(PRE ? relu_f(xraw) : xraw, to_f<CT>(gv[j].v[k]), div, s, z,
+            const float xraw = to_f<XT>(xv.v[k]);
+            float d = bwd_elem<CT, RM, MODE, ZP0>(PRE ? relu_f(xraw) : xraw, to_f<CT>(gv.v[k]), div, s, z,
                                                   qmin, qmax, clamp_ste, mode, ds_acc, dzp_acc);
             if constexpr (PRE) d = xraw > 0.f ? d : 0.f;  // torch.relu backward: grad * (x > 0)
             dv.v[k] = from_f<XT>(d);
@@ -791,7 +965,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
           if constexpr (sizeof(XT) == 2 && VEC % 2 == 0 && !PRE) {
             // two 16-bit keys per word: clear both sign bits, packed unsigned max (2 ops per pair)
             typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-            const vec_t<uint32_t, VEC / 2> w = __builtin_bit_cast(vec_t<uint32_t, VEC / 2>, xv[j]);
+            const vec_t<uint32_t, VEC / 2> w = __builtin_bit_cast(vec_t<uint32_t, VEC / 2>, xv);
             u16x2 m2 = {0, 0};
 #pragma unroll
             for (int k = 0; k < VEC / 2; ++k)
@@ -802,12 +976,12 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
           } else {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-              const uint32_t b = pre_abs_bits<XT, PRE>(xv[j].v[k]);
+              const uint32_t b = pre_abs_bits<XT, PRE>(xv.v[k]);
               umax = b > umax ? b : umax;
             }
           }
         }
-        store_vec<XT, VEC, NT>(dxp + off[j], dv);
+        store_vec<XT, VEC, NT>(dxp + off, dv);
       }
     }
   }
@@ -876,8 +1050,9 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
   }
 }
 
+// (96 scalar registers: one more would cost a resident workgroup per CU -- MI355X_MICROARCH.md, Residency)
 template <typename XT, typename CT, int VEC, int RM, int MODE, bool NT>
-__global__ __launch_bounds__(kBlock) void fakequant_bwd_kernel(QuantArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void fakequant_bwd_kernel(QuantArgs a) {
   const Unit u = locate_unit(a.t);
   if (!u.valid) return;
   float s, z;
@@ -1391,21 +1566,8 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
 
 // ---- statistic + quantizer in one launch ------------------------------------------------------------
 struct FusedPlan {
-  int vec_ok;
-  int32_t cpr, spr, slices, waves, team, nteams;
+  int32_t cpr, spr, slices, waves, nblocks;
 };
-
-static int g_fused_max_team = -1;  // -1: BVQ_FUSED_MAX_TEAM or 1
-static int fused_max_team() {
-  static const int from_env = env_flag("BVQ_FUSED_MAX_TEAM", 1);
-  return g_fused_max_team >= 0 ? g_fused_max_team : from_env;
-}
-
-extern "C" int bvq_set_fused_max_team(int workgroups) {
-  const int old = fused_max_team();
-  g_fused_max_team = workgroups;
-  return old;
-}
 
 static int num_cus() {
   static int n = [] {
@@ -1418,50 +1580,161 @@ static int num_cus() {
   return n;
 }
 
-// the fused form applies when a channel fits the registers of a team that still leaves room for several
-// teams on the chip; everything else takes the two-kernel route
-static bool fused_plan(const bvq_quant_desc* d, const void* x, const void* y, FusedPlan& p) {
+struct FusedShape {
+  bool ok;
+  int64_t outer, channels, inner;
+  int vec;
+};
+
+// what both one-launch forms need: x and y of one dtype, dequantized output, whole 16-byte chunks
+static FusedShape fused_shape(const bvq_quant_desc* d, const void* x, const void* y) {
+  FusedShape f = {};
   static const int enabled = env_flag("BVQ_FUSED_FWD", 1);
-  if (!enabled) return false;
-  if (d->x_dtype != d->ct_dtype || d->out_kind != BVQ_OUT_DEQUANT) return false;
-  if (d->zp_per_channel) return false;
+  if (!enabled) return f;
+  if (d->x_dtype != d->ct_dtype || d->out_kind != BVQ_OUT_DEQUANT) return f;
+  if (d->zp_per_channel) return f;
   const bool pc = d->scale_per_channel && d->channels > 1;
-  const int64_t outer = pc ? d->outer : 1;
-  const int64_t channels = pc ? d->channels : 1;
-  const int64_t inner = pc ? d->inner : d->outer * d->channels * d->inner;
-  const int vec = 16 / dtype_size(d->x_dtype);
-  if (inner <= 0 || outer <= 0 || inner % vec != 0) return false;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return false;
-  const int64_t cpr = inner / vec;
+  f.outer = pc ? d->outer : 1;
+  f.channels = pc ? d->channels : 1;
+  f.inner = pc ? d->inner : d->outer * d->channels * d->inner;
+  f.vec = 16 / dtype_size(d->x_dtype);
+  if (f.inner <= 0 || f.outer <= 0 || f.inner % f.vec != 0) return f;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return f;
+  f.ok = true;
+  return f;
+}
+
+// the register-resident form applies when a channel fits the registers of ONE workgroup
+static bool fused_plan(const bvq_quant_desc* d, const void* x, const void* y, FusedPlan& p) {
+  const FusedShape f = fused_shape(d, x, y);
+  if (!f.ok) return false;
+  const int64_t cpr = f.inner / f.vec;
   const int64_t spr = (cpr + kFusedSliceChunks - 1) / kFusedSliceChunks;
-  const int64_t slices = outer * spr;
-  if (cpr > (1 << 30) || slices > (1 << 20)) return false;
-  const int waves = slices < kFusedMaxWaves ? (int)slices : kFusedMaxWaves;
-  const int64_t team = (slices + waves - 1) / waves;
-  // residency budget: 2 workgroups of 512 threads per CU (or the same number of waves in smaller ones)
-  const int64_t budget = (int64_t)num_cus() * 2 * kFusedMaxWaves / waves;
-  const int64_t nteams_max = budget / team;
-  if (nteams_max < 4 && nteams_max < channels) return false;  // the channel is too large to be worth it
-  // Teams of several workgroups are correct (tests/test_gpu_fused_fwd.py) but latency-bound: on the
-  // [256,512,56,56] activation (teams of 32) a round of 16 channels takes ~33 us where its 25 MB need 4 us
-  // of HBM time -- 1.05 ms against 0.40 ms for the two streaming kernels (profiles/r01_microbench_v4.txt).
-  // So by default only channels that fit ONE workgroup take this route; BVQ_FUSED_MAX_TEAM lifts the limit.
-  if (team > fused_max_team()) return false;
+  const int64_t slices = f.outer * spr;
+  if (cpr > (1 << 30) || slices > kFusedMaxWaves) return false;
   p.cpr = (int32_t)cpr;
   p.spr = (int32_t)spr;
   p.slices = (int32_t)slices;
-  p.waves = waves;
-  p.team = (int32_t)team;
-  p.nteams = (int32_t)(nteams_max < channels ? nteams_max : channels);
+  p.waves = (int)slices;
+  // residency budget: 2 workgroups of 512 threads per CU (or the same number of waves in smaller ones)
+  const int64_t budget = (int64_t)num_cus() * 2 * kFusedMaxWaves / p.waves;
+  p.nblocks = (int32_t)(budget < f.channels ? budget : f.channels);
   return true;
+}
+
+// the slab pipeline applies to per-channel tensors too large for the Infinity Cache to serve the
+// two-kernel route's second read of x
+struct PipePlan {
+  int32_t cps, nslab, lag, rpu_s, nob_s, rpu_q, nob_q, bs, bq;
+  int snt, qntl, qnts;
+  int64_t lds_bytes;
+};
+
+static int64_t env_i64(const char* name, int64_t dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoll(v) : dflt;
+}
+
+static bool pipe_plan(const bvq_quant_desc* d, const void* x, const void* y, PipePlan& p) {
+  const FusedShape f = fused_shape(d, x, y);
+  if (!f.ok || f.channels < 2) return false;
+  if (!env_i64("BVQ_PIPE", 1)) return false;
+  const int es = dtype_size(d->x_dtype);
+  const int64_t row_bytes = f.inner * es;
+  const int64_t chan_bytes = f.outer * row_bytes;
+  const int64_t total = chan_bytes * f.channels;
+  // rows long enough for the row-mapped units, a tensor that does not fit the cache next to its output
+  if (row_bytes < 1024 || f.inner > (1 << 24) || f.outer > (1 << 20)) return false;
+  if (total < env_i64("BVQ_PIPE_MIN_MB", 192) * (1ll << 20)) return false;
+  const int64_t slab_bytes = env_i64("BVQ_PIPE_SLAB_KB", 12 * 1024) * 1024;
+  const int64_t lag_bytes = env_i64("BVQ_PIPE_LAG_KB", 96 * 1024) * 1024;
+  int64_t cps = slab_bytes / chan_bytes;
+  if (cps < 1) cps = 1;
+  if (cps > f.channels) cps = f.channels;
+  if (cps * chan_bytes > 64ll << 20) return false;  // one channel alone outgrows the cache window
+  const int64_t nslab = (f.channels + cps - 1) / cps;
+  int64_t lag = (lag_bytes + cps * chan_bytes - 1) / (cps * chan_bytes);
+  if (lag < 1) lag = 1;
+  if (nslab < 2 * lag + 2) return false;  // too few slabs for the pipeline to pay
+  const int64_t cpr = f.inner / f.vec;
+  // rows per unit: the statistic takes ~16 KiB per wave, the quantizer the fewest rows that keep >= 86 % of
+  // the lanes of its 64-wide accesses busy (make_tiling's rules)
+  int64_t rpu_s = env_i64("BVQ_PIPE_RPU_S", 0);
+  if (rpu_s <= 0) {
+    rpu_s = (16384 + row_bytes - 1) / row_bytes;
+    if (rpu_s < 1) rpu_s = 1;
+  }
+  if (rpu_s > f.outer) rpu_s = f.outer;
+  int64_t rpu_q = 1;
+  for (int64_t r = 1; r <= f.outer && r <= 64; ++r) {
+    const int64_t loads = (r * cpr + kWave - 1) / kWave;
+    rpu_q = r;
+    if ((double)(r * cpr) / (double)(loads * kWave) >= 0.86) break;
+  }
+  if (cpr >= kWave) rpu_q = 1;
+  const int64_t nob_s = (f.outer + rpu_s - 1) / rpu_s, nob_q = (f.outer + rpu_q - 1) / rpu_q;
+  const int64_t bs = (nob_s * cps + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t bq = (nob_q * cps + kWavesPerBlock - 1) / kWavesPerBlock;
+  if ((nslab + lag) * (bs + bq) >= (1ll << 31)) return false;
+  p.cps = (int32_t)cps;
+  p.nslab = (int32_t)nslab;
+  p.lag = (int32_t)lag;
+  p.rpu_s = (int32_t)rpu_s;
+  p.nob_s = (int32_t)nob_s;
+  p.rpu_q = (int32_t)rpu_q;
+  p.nob_q = (int32_t)nob_q;
+  p.bs = (int32_t)bs;
+  p.bq = (int32_t)bq;
+  p.snt = (int)env_i64("BVQ_PIPE_SNT", 0);
+  p.qntl = (int)env_i64("BVQ_PIPE_QNTL", 1);
+  p.qnts = (int)env_i64("BVQ_PIPE_QNTS", 1);
+  p.lds_bytes = env_i64("BVQ_PIPE_LDS_KB", 0) * 1024;
+  if (p.lds_bytes < 0 || p.lds_bytes > 64 * 1024) p.lds_bytes = 0;  // above 64 KiB needs an opt-in attribute
+  return true;
+}
+
+static int64_t pipe_workspace_words(const PipePlan& p, int64_t channels) {
+  return channels + (int64_t)p.nslab * kPipeShards + 4;
 }
 
 extern "C" int64_t bvq_stats_fakequant_fwd_workspace_bytes(const bvq_quant_desc* d, const void* x, const void* y) {
   if (validate(d)) return -1;
   FusedPlan p;
-  if (!fused_plan(d, x, y, p)) return 0;  // not applicable: use bvq_absmax_scale + bvq_fakequant_fwd
-  const int64_t channels = (d->scale_per_channel && d->channels > 1) ? d->channels : 1;
-  return (2 * channels + 4) * (int64_t)sizeof(uint32_t);
+  if (fused_plan(d, x, y, p)) return 16;  // no workspace needed; non-zero says "covered"
+  PipePlan pp;
+  if (pipe_plan(d, x, y, pp)) return pipe_workspace_words(pp, d->channels) * (int64_t)sizeof(uint32_t);
+  return 0;  // not applicable: use bvq_absmax_scale + bvq_fakequant_fwd
+}
+
+template <typename T>
+static void launch_pipe(const PipeArgs& a, const PipePlan& p, bool rne, hipStream_t st) {
+  const dim3 grid((unsigned)((int64_t)(p.nslab + p.lag) * (p.bs + p.bq))), block(kBlock);
+  // unused dynamic LDS caps the resident workgroups per CU (160 KiB / lds): fewer waves in flight means a
+  // statistic unit finishes sooner after its dispatch, so a shorter lag keeps the slab inside the cache
+  const size_t lds = (size_t)p.lds_bytes;
+#define BVQ_PIPE_RM(SNT, QNTL, QNTS)                                                            \
+  do {                                                                                          \
+    if (rne)                                                                                    \
+      pipe_absmax_fakequant_kernel<T, BVQ_ROUND, SNT, QNTL, QNTS><<<grid, block, lds, st>>>(a); \
+    else                                                                                        \
+      pipe_absmax_fakequant_kernel<T, kAnyRM, SNT, QNTL, QNTS><<<grid, block, lds, st>>>(a);    \
+  } while (0)
+#ifdef BVQ_PIPE_EXPERIMENT
+  const int v = (p.snt ? 4 : 0) | (p.qntl ? 2 : 0) | (p.qnts ? 1 : 0);
+  switch (v) {
+    case 0: BVQ_PIPE_RM(false, false, false); break;
+    case 1: BVQ_PIPE_RM(false, false, true); break;
+    case 2: BVQ_PIPE_RM(false, true, false); break;
+    case 3: BVQ_PIPE_RM(false, true, true); break;
+    case 4: BVQ_PIPE_RM(true, false, false); break;
+    case 5: BVQ_PIPE_RM(true, false, true); break;
+    case 6: BVQ_PIPE_RM(true, true, false); break;
+    default: BVQ_PIPE_RM(true, true, true); break;
+  }
+#else
+  BVQ_PIPE_RM(false, true, true);
+#endif
+#undef BVQ_PIPE_RM
 }
 
 extern "C" int bvq_stats_fakequant_fwd(const bvq_quant_desc* d, const void* x, double min_val, int use_min,
@@ -1469,54 +1742,39 @@ extern "C" int bvq_stats_fakequant_fwd(const bvq_quant_desc* d, const void* x, d
                                        void* workspace, int64_t workspace_bytes, bvq_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
-  FusedPlan p;
   if (!x || !y || !stat_out || !scale_out || !workspace) {
     set_error("bvq_stats_fakequant_fwd: null pointer");
     return BVQ_ERR_INVALID;
   }
-  if (!fused_plan(d, x, y, p)) {
-    set_error("bvq_stats_fakequant_fwd: shape / layout not covered by the one-kernel form");
-    return BVQ_ERR_UNSUPPORTED;
-  }
+  hipStream_t st = (hipStream_t)stream;
   const bool pc = d->scale_per_channel && d->channels > 1;
   const int64_t channels = pc ? d->channels : 1;
-  if (workspace_bytes < (2 * channels + 4) * (int64_t)sizeof(uint32_t)) {
-    set_error("bvq_stats_fakequant_fwd: workspace too small");
-    return BVQ_ERR_WORKSPACE;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  FusedArgs a = {};
-  a.x = x;
-  a.y = y;
-  a.stat_out = stat_out;
-  a.scale_out = scale_out;
-  a.stat_bits = reinterpret_cast<uint32_t*>(workspace);
-  a.arrive = a.stat_bits + channels;
-  a.error = a.arrive + channels;
-  a.outer = pc ? d->outer : 1;
-  a.inner = pc ? d->inner : d->outer * d->channels * d->inner;
-  a.channels = (int32_t)channels;
-  a.cpr = p.cpr;
-  a.spr = p.spr;
-  a.slices = p.slices;
-  a.team = p.team;
-  a.nteams = p.nteams;
-  a.qmin = d->qmin;
-  a.qmax = d->qmax;
-  a.min_val = round_host((float)min_val, d->x_dtype);  // python scalar -> the statistic's dtype
-  a.use_min = use_min;
-  a.int_threshold = (float)int_threshold;
-  a.scale_dtype = d->scale_dtype;
-  a.scale_pc = pc ? 1 : 0;
-  a.scalar_cast = d->scalar_mode == BVQ_SCALAR_CAST;
-  a.round_mode = d->round_mode;
-  a.pre_relu = d->pre_op == BVQ_PRE_RELU;
-  if (p.team > 1) {
-    const int64_t words = 2 * channels + 4;
-    fused_zero_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(a.stat_bits, words);
-  }
-  const dim3 grid((unsigned)((int64_t)p.team * p.nteams)), block((unsigned)(p.waves * kWave));
   const bool rne = d->round_mode == BVQ_ROUND;
+  FusedPlan p;
+  PipePlan pp;
+  if (fused_plan(d, x, y, p)) {
+    FusedArgs a = {};
+    a.x = x;
+    a.y = y;
+    a.stat_out = stat_out;
+    a.scale_out = scale_out;
+    a.outer = pc ? d->outer : 1;
+    a.inner = pc ? d->inner : d->outer * d->channels * d->inner;
+    a.channels = (int32_t)channels;
+    a.cpr = p.cpr;
+    a.spr = p.spr;
+    a.slices = p.slices;
+    a.qmin = d->qmin;
+    a.qmax = d->qmax;
+    a.min_val = round_host((float)min_val, d->x_dtype);  // python scalar -> the statistic's dtype
+    a.use_min = use_min;
+    a.int_threshold = (float)int_threshold;
+    a.scale_dtype = d->scale_dtype;
+    a.scale_pc = pc ? 1 : 0;
+    a.scalar_cast = d->scalar_mode == BVQ_SCALAR_CAST;
+    a.round_mode = d->round_mode;
+    a.pre_relu = d->pre_op == BVQ_PRE_RELU;
+    const dim3 grid((unsigned)p.nblocks), block((unsigned)(p.waves * kWave));
 #define BVQ_FUSED(T)                                                        \
   do {                                                                      \
     if (rne)                                                                \
@@ -1524,14 +1782,57 @@ extern "C" int bvq_stats_fakequant_fwd(const bvq_quant_desc* d, const void* x, d
     else                                                                    \
       fused_absmax_fakequant_kernel<T, kAnyRM><<<grid, block, 0, st>>>(a);   \
   } while (0)
-  if (d->x_dtype == BVQ_F32)
-    BVQ_FUSED(float);
-  else if (d->x_dtype == BVQ_BF16)
-    BVQ_FUSED(bf16_t);
-  else
-    BVQ_FUSED(f16_t);
+    if (d->x_dtype == BVQ_F32)
+      BVQ_FUSED(float);
+    else if (d->x_dtype == BVQ_BF16)
+      BVQ_FUSED(bf16_t);
+    else
+      BVQ_FUSED(f16_t);
 #undef BVQ_FUSED
-  return check_launch("bvq_stats_fakequant_fwd");
+    return check_launch("bvq_stats_fakequant_fwd");
+  }
+  if (!pipe_plan(d, x, y, pp)) {
+    set_error("bvq_stats_fakequant_fwd: shape / layout not covered by the one-launch forms");
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  const int64_t words = pipe_workspace_words(pp, channels);
+  if (workspace_bytes < words * (int64_t)sizeof(uint32_t)) {
+    set_error("bvq_stats_fakequant_fwd: workspace too small");
+    return BVQ_ERR_WORKSPACE;
+  }
+  PipeArgs a = {};
+  a.q.x = x;
+  a.q.y = y;
+  fill_args(a.q, d);
+  a.q.out_int = 0;
+  a.stat_out = stat_out;
+  a.scale_out = scale_out;
+  a.stat_bits = reinterpret_cast<uint32_t*>(workspace);
+  a.done = a.stat_bits + channels;
+  a.outer = d->outer;
+  a.inner = d->inner;
+  a.channels = (int32_t)channels;
+  a.cps = pp.cps;
+  a.nslab = pp.nslab;
+  a.lag = pp.lag;
+  a.rpu_s = pp.rpu_s;
+  a.nob_s = pp.nob_s;
+  a.rpu_q = pp.rpu_q;
+  a.nob_q = pp.nob_q;
+  a.bs = pp.bs;
+  a.bq = pp.bq;
+  a.min_val = round_host((float)min_val, d->x_dtype);
+  a.int_threshold = (float)int_threshold;
+  a.use_min = use_min;
+  a.spin_limit = (int32_t)env_i64("BVQ_PIPE_SPIN_LIMIT", kPipeSpinLimit);
+  fused_zero_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(a.stat_bits, words);
+  if (d->x_dtype == BVQ_F32)
+    launch_pipe<float>(a, pp, rne, st);
+  else if (d->x_dtype == BVQ_BF16)
+    launch_pipe<bf16_t>(a, pp, rne, st);
+  else
+    launch_pipe<f16_t>(a, pp, rne, st);
+  return check_launch("bvq_stats_fakequant_fwd/pipeline");
 }
 
 #endif  // forward part

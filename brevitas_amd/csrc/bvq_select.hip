@@ -19,6 +19,13 @@
 
 namespace bvq {
 
+// Bin counters are uint32 end to end (per-wave LDS bins, the global histograms, the all-reduced shard sums): a bin
+// may hold every element of a channel (a constant tensor, post-ReLU zeros), so a channel -- over ALL shards of a
+// batch-sharded tensor -- must have fewer than 2^32 elements.  Enforced here per call and, for the shard count,
+// by brevitas_amd.distributed.sharded_kth_value.
+constexpr int64_t kSelMaxCount = 0xFFFFFFFFll;
+
+
 constexpr int kDigitBits = 11;
 constexpr int kBins = 1 << kDigitBits;
 constexpr int kSelUnroll = 4;
@@ -484,6 +491,11 @@ extern "C" int bvq_kth_hist(int abs_key, int dtype, const void* x, int64_t outer
     return BVQ_ERR_INVALID;
   }
   if (outer * inner == 0) return BVQ_OK;  // an empty shard adds nothing to the histogram
+  if (outer * inner > kSelMaxCount) {
+    set_error("bvq_kth_hist: %lld elements per channel; the digit counters are 32-bit (limit 2^32 - 1 over all shards)",
+              (long long)(outer * inner));
+    return BVQ_ERR_UNSUPPORTED;
+  }
   if (!x) {
     set_error("bvq_kth_hist: null pointer");
     return BVQ_ERR_INVALID;
@@ -645,6 +657,11 @@ extern "C" int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t oute
     return BVQ_ERR_INVALID;
   }
   const int64_t per_channel = outer * inner;
+  if (per_channel > kSelMaxCount) {
+    set_error("bvq_kth_value: %lld elements per channel; the digit counters are 32-bit (limit 2^32 - 1)",
+              (long long)per_channel);
+    return BVQ_ERR_UNSUPPORTED;
+  }
   if (k < 1 || k > per_channel) {  // torch.kthvalue: "selected index k out of range"
     set_error("bvq_kth_value: k = %lld out of range [1, %lld]", (long long)k, (long long)per_channel);
     return BVQ_ERR_INVALID;
@@ -672,6 +689,11 @@ extern "C" int bvq_kth_pair(int abs_key, int dtype, const void* x, int64_t outer
     return BVQ_ERR_INVALID;
   }
   const int64_t per_channel = outer * inner;
+  if (per_channel > kSelMaxCount) {
+    set_error("bvq_kth_pair: %lld elements per channel; the digit counters are 32-bit (limit 2^32 - 1)",
+              (long long)per_channel);
+    return BVQ_ERR_UNSUPPORTED;
+  }
   if (k_first < 1 || k_first > per_channel || k_second < 1 || k_second > per_channel) {
     set_error("bvq_kth_pair: rank out of range [1, %lld]", (long long)per_channel);
     return BVQ_ERR_INVALID;

@@ -24,6 +24,7 @@ struct StatArgs {
   const void* x;
   uint32_t* part_a;  // ABSMAX: abs bits (as a float32 pattern) ; MINMAX: max as float bits
   uint32_t* part_b;  // MINMAX: min as float bits
+  float* pivot;      // moments: [channels] the value the sums are shifted by (written by the kernel)
 };
 
 template <typename T, int VEC, bool NT, bool RELU>
@@ -120,14 +121,24 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(StatArgs a) {
 }
 
 // ---- first and second moment of |x| (AbsAve, MeanSigmaStd, B/core/stats/stats_op.py:186-262) -------
-// One streaming read: per-unit float32 partial sums of |x| and x^2 (a lane adds ~64 values, the wave
-// reduce and everything after it run in double), combined by the fixed-order channel sums.
+// One streaming read: per-unit float32 partial sums of d = |x| - p and d^2, combined by the fixed-order
+// channel sums (double).  p is the channel's PIVOT, |x| of its first element (0 if that is not finite):
+// the variance (sum d^2 - (sum d)^2 / n) / (n - 1) of the shifted values does not cancel when the mean of
+// |x| is far larger than its spread (|x| = 100 +- 0.01), where sum x^2 - (sum |x|)^2 / n of float32 sums
+// is garbage.  torch.var itself is a two-pass / Welford computation.
+template <typename T>
+__device__ __forceinline__ float moments_pivot(const void* x, int64_t first) {
+  const float p = fabsf(to_f<T>(reinterpret_cast<const T*>(x)[first]));
+  return p <= 3.4028234663852886e38f ? p : 0.f;  // inf / NaN: no shift
+}
+
 template <typename T, int VEC, bool NT>
 __global__ __launch_bounds__(kBlock) void absmoments_kernel(StatArgs a) {
   const Unit u = locate_unit(a.t);
   if (!u.valid) return;
   const int lane = threadIdx.x & 63;
   const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + u.base;
+  const float p = moments_pivot<T>(a.x, (int64_t)u.channel * a.t.row_len);
   float s1 = 0.f, s2 = 0.f;
   ChunkWalker cur;
   cur.init(u, VEC, lane);
@@ -146,24 +157,25 @@ __global__ __launch_bounds__(kBlock) void absmoments_kernel(StatArgs a) {
       if (ok[j]) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          const float f = fabsf(to_f<T>(xv[j].v[k]));
-          s1 += f;
-          s2 += f * f;
+          const float d = fabsf(to_f<T>(xv[j].v[k])) - p;
+          s1 += d;
+          s2 += d * d;
         }
       }
     }
   }
   const int64_t i = (int64_t)cur.cpr * VEC + lane;
   if (u.nrows == 1 && i < u.len) {
-    const float f = fabsf(to_f<T>(xp[i]));
-    s1 += f;
-    s2 += f * f;
+    const float d = fabsf(to_f<T>(xp[i])) - p;
+    s1 += d;
+    s2 += d * d;
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   if (lane == 0) {
     a.part_a[u.id] = __builtin_bit_cast(uint32_t, s1);
     a.part_b[u.id] = __builtin_bit_cast(uint32_t, s2);
+    if (u.base == (int64_t)u.channel * a.t.row_len) a.pivot[u.channel] = p;  // the channel's first unit
   }
 }
 
@@ -976,7 +988,7 @@ extern "C" int bvq_abs_moments(int dtype, const void* x, int64_t outer, int64_t 
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = outer * channels * inner;
   if (n == 0) {  // an empty sum
-    (void)hipMemsetAsync(sums, 0, 2 * sizeof(float) * channels, st);
+    (void)hipMemsetAsync(sums, 0, 3 * sizeof(float) * channels, st);
     return BVQ_OK;
   }
   if (!x || !workspace) {
@@ -995,6 +1007,7 @@ extern "C" int bvq_abs_moments(int dtype, const void* x, int64_t outer, int64_t 
   a.x = x;
   a.part_a = reinterpret_cast<uint32_t*>(workspace);
   a.part_b = a.part_a + a.t.units;
+  a.pivot = sums + 2 * channels;
   const bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
   const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
 #define BVQ_MOM(T)                                                     \

@@ -67,9 +67,19 @@ def sync_stat_min(stat_f32: Tensor, group) -> Tensor:
     return stat_f32
 
 
+KTH_MAX_COUNT = 2 ** 32 - 1
+
+
 def sharded_kth_value(steps, group) -> Tensor:
     """k-th value of the concatenation of all shards.  `steps`: brevitas_amd._native.KthSelectSteps over
     this shard (or any object with its begin / hist(p) / pick(p) / finish and `passes`)."""
+    # the digit counters are 32-bit and the all-reduced ones count every shard's elements (include/bvq.h):
+    # refuse a channel that could overflow them instead of selecting a wrong value silently
+    world = dist.get_world_size(group)
+    local = getattr(steps, 'per_channel', 0)
+    if local * world > KTH_MAX_COUNT:
+        raise ValueError('sharded_kth_value: %d elements per channel on this shard x %d shards exceeds the '
+                         '32-bit digit counters of the radix select (limit 2^32 - 1 over all shards)' % (local, world))
     steps.begin()
     for p in range(steps.passes):
         h = steps.hist(p)

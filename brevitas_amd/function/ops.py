@@ -1,12 +1,13 @@
 """Plain (non straight-through) quantization primitives -- mirror of B/function/ops.py:16-191.
 
-Tensor math runs in libbvq.so; the integer-range formulas are scalar arithmetic on the 0-dim
-bit-width tensor, exactly as in the reference.
+Tensor math runs in libbvq.so (CPU tensors: the pure-torch route, brevitas_amd._aten); the integer-range
+formulas are scalar arithmetic on the 0-dim bit-width tensor, exactly as in the reference.
 """
 import torch
 from torch import Tensor
 from torch.autograd import Function
 
+from .. import _aten
 from .. import _native as nat
 
 __all__ = ['binary_sign', 'round_to_zero', 'dpu_round', 'tensor_clamp', 'tensor_clamp_', 'identity', 'max_int',
@@ -18,7 +19,7 @@ class _ZeroGradUnaryFn(Function):
 
     @staticmethod
     def forward(ctx, x, op):
-        return nat.unary(op, x)
+        return _aten.for_tensor(x).unary(op, x)
 
     @staticmethod
     def backward(ctx, grad_y):
@@ -31,27 +32,27 @@ class _TensorClampFn(Function):
     @staticmethod
     def forward(ctx, x, min_val, max_val):
         ctx.save_for_backward(x, min_val, max_val)
-        return nat.tensor_clamp(x, min_val, max_val).reshape(x.shape)
+        return _aten.for_tensor(x).tensor_clamp(x, min_val, max_val).reshape(x.shape)
 
     @staticmethod
     def backward(ctx, grad_y):
         x, min_val, max_val = ctx.saved_tensors
-        return nat.tensor_clamp_bwd(grad_y, x, min_val, max_val).reshape(x.shape), None, None
+        return _aten.for_tensor(x).tensor_clamp_bwd(grad_y, x, min_val, max_val).reshape(x.shape), None, None
 
 
 def binary_sign(x: Tensor) -> Tensor:
     """2-valued sign, +1 at 0 (B/function/ops.py:16-34)"""
-    return _ZeroGradUnaryFn.apply(x, nat.OP_BINARY_SIGN) if x.requires_grad else nat.unary(nat.OP_BINARY_SIGN, x)
+    return _ZeroGradUnaryFn.apply(x, nat.OP_BINARY_SIGN) if x.requires_grad else _aten.for_tensor(x).unary(nat.OP_BINARY_SIGN, x)
 
 
 def round_to_zero(x: Tensor) -> Tensor:
     """sign(x) * floor(|x|) (B/function/ops.py:37-53)"""
-    return _ZeroGradUnaryFn.apply(x, nat.OP_ROUND_TO_ZERO) if x.requires_grad else nat.unary(nat.OP_ROUND_TO_ZERO, x)
+    return _ZeroGradUnaryFn.apply(x, nat.OP_ROUND_TO_ZERO) if x.requires_grad else _aten.for_tensor(x).unary(nat.OP_ROUND_TO_ZERO, x)
 
 
 def dpu_round(x: Tensor) -> Tensor:
     """DPU rounding (B/function/ops.py:56-72)"""
-    return _ZeroGradUnaryFn.apply(x, nat.OP_DPU_ROUND) if x.requires_grad else nat.unary(nat.OP_DPU_ROUND, x)
+    return _ZeroGradUnaryFn.apply(x, nat.OP_DPU_ROUND) if x.requires_grad else _aten.for_tensor(x).unary(nat.OP_DPU_ROUND, x)
 
 
 def tensor_clamp(x: Tensor, min_val: Tensor, max_val: Tensor) -> Tensor:
@@ -70,7 +71,7 @@ def tensor_clamp_(x: Tensor, min_val: Tensor, max_val: Tensor) -> Tensor:
     """In-place variant, not differentiable (B/function/ops.py:103-111)"""
     if not x.is_contiguous():
         raise nat.BvqError('tensor_clamp_: in-place clamp needs a contiguous tensor')
-    nat.tensor_clamp(x, min_val, max_val, out=x)
+    _aten.for_tensor(x).tensor_clamp(x, min_val, max_val, out=x)
     return x
 
 

@@ -3,11 +3,13 @@
 Same 12 callables and the same argument meaning as the reference's two interchangeable backends
 (Python: B/ops/autograd_ste_ops.py:385-431; C++: B/csrc/autograd_ste_ops.cpp:197-271): every forward
 is one HIP elementwise kernel, every backward is the straight-through identity w.r.t. the first
-argument (binary_sign(x) * grad for abs_binary_sign_grad).  Tensors must live on a ROCm device.
+argument (binary_sign(x) * grad for abs_binary_sign_grad).  A CPU tensor takes the pure-torch route
+(brevitas_amd._aten: the reference's own op composition), as the reference's backends do.
 """
 import torch
 from torch.autograd import Function
 
+from .. import _aten
 from .. import _native as nat
 
 __all__ = [
@@ -21,7 +23,7 @@ __all__ = [
 
 def _unary_ste(name, op, doc):
     def forward(ctx, x):
-        return nat.unary(op, x)
+        return _aten.for_tensor(x).unary(op, x)
 
     def backward(ctx, grad_y):
         return grad_y
@@ -44,7 +46,7 @@ class ScalarClampSteFn(Function):
 
     @staticmethod
     def forward(ctx, x, min_val, max_val):
-        return nat.scalar_clamp(x, min_val, max_val)
+        return _aten.for_tensor(x).scalar_clamp(x, min_val, max_val)
 
     @staticmethod
     def backward(ctx, grad_y):
@@ -56,7 +58,7 @@ class ScalarClampMinSteFn(Function):
 
     @staticmethod
     def forward(ctx, x, min_val):
-        return nat.scalar_clamp(x, min_val, None)
+        return _aten.for_tensor(x).scalar_clamp(x, min_val, None)
 
     @staticmethod
     def backward(ctx, grad_y):
@@ -68,7 +70,7 @@ class TensorClampSteFn(Function):
 
     @staticmethod
     def forward(ctx, x, min_val, max_val):
-        return nat.tensor_clamp(x, min_val, max_val)
+        return _aten.for_tensor(x).tensor_clamp(x, min_val, max_val)
 
     @staticmethod
     def backward(ctx, grad_y):
@@ -82,7 +84,7 @@ class InplaceTensorClampSteFn(Function):
     def forward(ctx, x, min_val, max_val):
         if not x.is_contiguous():
             raise nat.BvqError('tensor_clamp_ste_: in-place clamp needs a contiguous tensor')
-        nat.tensor_clamp(x, min_val, max_val, out=x)
+        _aten.for_tensor(x).tensor_clamp(x, min_val, max_val, out=x)
         ctx.mark_dirty(x)
         return x
 
@@ -97,12 +99,12 @@ class AbsBinarySignGradFn(Function):
     @staticmethod
     def forward(ctx, x):
         ctx.save_for_backward(x)
-        return nat.unary(nat.OP_ABS, x)
+        return _aten.for_tensor(x).unary(nat.OP_ABS, x)
 
     @staticmethod
     def backward(ctx, grad_y):
         x, = ctx.saved_tensors
-        return nat.abs_binary_sign_grad_bwd(grad_y, x).reshape(x.shape)
+        return _aten.for_tensor(x).abs_binary_sign_grad_bwd(grad_y, x).reshape(x.shape)
 
 
 round_ste_impl = RoundSteFn.apply

@@ -181,7 +181,7 @@ def Int8WeightPerTensorFixedPoint(weights, bit_width: int = 8) -> RescalingIntQu
     return RescalingIntQuant(
         IntQuant(narrow_range=True, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClampSte()),
         StatsFromParameterScaling(AbsMax(), OverTensorView(), 0, tracked, _pot(), (), affine_rescaling=False,
-                                  scaling_min_val=None),
+                                  scaling_min_val=SCALING_MIN_VAL),
         PowerOfTwoIntScaling(signed=True), ZeroZeroPoint(), BitWidthConst(bit_width))
 
 
@@ -193,7 +193,7 @@ def Int8WeightPerChannelFixedPoint(weights, bit_width: int = 8) -> RescalingIntQ
     return RescalingIntQuant(
         IntQuant(narrow_range=True, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClampSte()),
         StatsFromParameterScaling(AbsMax(1), OverOutputChannelView(None), 1, tracked, _pot(), shape,
-                                  affine_rescaling=False, scaling_min_val=None),
+                                  affine_rescaling=False, scaling_min_val=SCALING_MIN_VAL),
         PowerOfTwoIntScaling(signed=True), ZeroZeroPoint(), BitWidthConst(bit_width))
 
 
@@ -266,5 +266,5 @@ def Int8BiasPerTensorFixedPointInternalScaling(bias: torch.nn.Parameter, bit_wid
     return RescalingIntQuant(
         IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
         StatsFromParameterScaling(AbsMax(), OverTensorView(), 0, [bias], _pot(), (), affine_rescaling=False,
-                                  scaling_min_val=None),
+                                  scaling_min_val=SCALING_MIN_VAL),
         PowerOfTwoIntScaling(signed=True), ZeroZeroPoint(), BitWidthConst(bit_width))

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BVQ_ABI_VERSION 1
+#define BVQ_ABI_VERSION 2
 
 typedef void* bvq_stream_t; /* hipStream_t */
 
@@ -217,11 +217,14 @@ int bvq_shard_unpack(const double* gathered, int world, int64_t channels, int ra
                      float* dscale_total, int64_t* tie_info, int64_t* total_ties, bvq_stream_t stream);
 
 /* ---- moment statistics ---------------------------------------------------------------------------
- * sums[c] = SUM |x|, sums[channels + c] = SUM x^2 over the `outer` and `inner` axes, as float32 (per-unit
- * float32 partials, double accumulation across units, fixed order): what AbsAve (mean |x|) and
- * MeanSigmaStd / MeanLearnedSigmaStd (mean |x| + sigma * sqrt(var |x| + eps)) need, in ONE read of x
- * instead of abs (read + write) + mean (read) + var (read) -- B/core/stats/stats_op.py:186-262.  The host
- * finishes on `channels` values.  Sums are order-dependent: equal to torch's within float32 rounding. */
+ * sums is float32 [3 * channels]: sums[c] = SUM d, sums[channels + c] = SUM d^2 over the `outer` and `inner`
+ * axes with d = |x| - p[c], and sums[2 * channels + c] = p[c], the channel's pivot (|x| of its first element,
+ * 0 if that is not finite); per-unit float32 partials, double accumulation across units, fixed order.  The
+ * host finishes on `channels` values:  mean |x| = p + SUM d / n,  var |x| = (SUM d^2 - (SUM d)^2 / n) / (n - 1)
+ * -- shifted sums, so the variance does not cancel when the mean is far larger than the spread.  That is
+ * what AbsAve (mean |x|) and MeanSigmaStd / MeanLearnedSigmaStd (mean |x| + sigma * sqrt(var |x| + eps))
+ * need, in ONE read of x instead of abs (read + write) + mean (read) + var (read) --
+ * B/core/stats/stats_op.py:186-262.  Sums are order-dependent: equal to torch's within float32 rounding. */
 int64_t bvq_abs_moments_workspace_bytes(int dtype, int64_t outer, int64_t channels, int64_t inner);
 int bvq_abs_moments(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner, float* sums,
                     void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
@@ -269,7 +272,9 @@ int bvq_kth_pair(int abs_key, int dtype, const void* x, int64_t outer, int64_t c
  * (B/core/stats/stats_op.py:56,84,114-116), clamped to [1, n] (torch.kthvalue raises for k = 0; callers
  * that need that error check q * n on the host).  Pass the same rule and q to bvq_kth_begin and to every
  * bvq_kth_pick.  The workspace (bvq_kth_workspace_bytes) depends on dtype and channels only.  Counters
- * are 32-bit: fewer than 2^32 elements per channel over all shards. */
+ * are 32-bit: fewer than 2^32 elements per channel over all shards -- bvq_kth_value / bvq_kth_pair /
+ * bvq_kth_hist return BVQ_ERR_UNSUPPORTED for a call that alone exceeds it; the caller of the sharded
+ * protocol checks (elements per channel on a shard) x (shards) before starting. */
 typedef enum bvq_kth_rule { BVQ_KTH_EXPLICIT = 0, BVQ_KTH_HIGH = 1, BVQ_KTH_LOW = 2 } bvq_kth_rule;
 int bvq_kth_passes(int dtype);
 int64_t bvq_kth_hist_offset(int dtype, int64_t channels, int pass);
@@ -350,17 +355,19 @@ int bvq_fakequant_fwd(const bvq_quant_desc* desc, const void* x, const void* sca
 /* Statistic AND quantizer in ONE launch: AbsMax over (outer, inner) -> clamp_min(min_val) -> / int_threshold
  * -> quantize-dequantize with that scale and a zero zero-point -- bvq_absmax_scale followed by
  * bvq_fakequant_fwd, i.e. RescalingIntQuant.forward on the stats-scaled graphs (B/core/quant/int.py:155-163,
- * B/core/scaling/runtime.py:50-72), reading x ONCE: a team of workgroups holds one channel in registers
- * between the reduction and the quantization (2 tensor passes instead of 3).  Uses desc's shape, dtypes
- * (x_dtype == ct_dtype), qmin/qmax, round_mode, scalar_mode, pre_op, scale_dtype / scale_per_channel;
- * zero-point is +0.  stat_out: [channels] in x's dtype, scale_out: [channels] in scale_dtype.
- * bvq_stats_fakequant_fwd_workspace_bytes returns 0 when the shape is not covered (a channel larger than the
- * team limit below allows, ragged rows, misaligned pointers): the caller then takes the two-call route. */
+ * B/core/scaling/runtime.py:50-72), in ONE launch, two forms:
+ *   - a channel that fits the registers of one workgroup (weights, small activations) is read ONCE: held in
+ *     registers between the reduction and the quantization (2 tensor passes instead of 3);
+ *   - a per-channel tensor too large for the 256 MiB Infinity Cache is walked as a slab pipeline: the statistic
+ *     of a slab of channels streams in from HBM while an earlier slab, still cache-resident, is quantized, so
+ *     HBM sees one read of x and one write of y.  Workgroups hand the statistic over through agent-scope
+ *     atomics; a quantizing wave whose slab's statistic has not arrived within a bounded number of polls
+ *     computes it from x itself, so the launch finishes under any dispatch order or residency.
+ * Uses desc's shape, dtypes (x_dtype == ct_dtype), qmin/qmax, round_mode, scalar_mode, pre_op, scale_dtype /
+ * scale_per_channel; zero-point is +0.  stat_out: [channels] in x's dtype, scale_out: [channels] in scale_dtype.
+ * bvq_stats_fakequant_fwd_workspace_bytes returns 0 when the shape is covered by neither form (ragged rows,
+ * misaligned pointers, mid-sized channels): the caller then takes the two-call route. */
 int64_t bvq_stats_fakequant_fwd_workspace_bytes(const bvq_quant_desc* desc, const void* x, const void* y);
-/* Largest team (workgroups per channel) the one-launch form may use; returns the previous value.  Default 1
- * (or BVQ_FUSED_MAX_TEAM): a channel that fits one workgroup needs no hand-off between workgroups.  Larger
- * teams are correct but latency-bound on MI355X; negative restores the default. */
-int bvq_set_fused_max_team(int workgroups);
 int bvq_stats_fakequant_fwd(const bvq_quant_desc* desc, const void* x, double min_val, int use_min,
                             double int_threshold, void* stat_out, void* scale_out, void* y, void* workspace,
                             int64_t workspace_bytes, bvq_stream_t stream);

@@ -639,15 +639,23 @@ def gen_fixed_point():
     from brevitas.core.stats import AbsPercentile
     st = Store('fixed_point')
     for dn in ('f32', 'bf16'):
-        # Int8WeightPerTensorFixedPoint, and the same with one radix point per output channel
-        for tag, per_channel in (('per_tensor', False), ('per_channel', True)):
+        # Int8WeightPerTensorFixedPoint, and the same with one radix point per output channel.  The injectors
+        # inherit MaxStatsScaling.scaling_min_val = 1e-10 (B/quant/base.py:52-57; PerTensorPoTScaling8bit,
+        # :185-191, does not override it): an all-zero channel gets the scale 1e-10 / 128 and exact zeros
+        for tag, per_channel in (('per_tensor', False), ('per_channel', True), ('per_channel_zero_row', True),
+                                 ('per_tensor_all_zero', False)):
             w = torch.nn.Parameter((torch.randn(12, 5, 3, 3) * 0.2).to(DT[dn]))
+            if tag == 'per_channel_zero_row':
+                w.data[3] = 0.0
+                w.data[7] = 0.0
+            if tag == 'per_tensor_all_zero':
+                w.data.zero_()
             if per_channel:
                 scaling = StatsFromParameterScaling(AbsMax(1), OverOutputChannelView(None), 1, [w],
-                                                    PowerOfTwoRestrictValue(CeilSte()), (12, 1, 1, 1), False, None)
+                                                    PowerOfTwoRestrictValue(CeilSte()), (12, 1, 1, 1), False, 1e-10)
             else:
                 scaling = StatsFromParameterScaling(AbsMax(), OverTensorView(), 0, [w],
-                                                    PowerOfTwoRestrictValue(CeilSte()), (), False, None)
+                                                    PowerOfTwoRestrictValue(CeilSte()), (), False, 1e-10)
             q = RescalingIntQuant(
                 IntQuant(narrow_range=True, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClampSte()),
                 scaling, PowerOfTwoIntScaling(signed=True), ZeroZeroPoint(), BitWidthConst(8))
@@ -655,6 +663,21 @@ def gen_fixed_point():
             g = torch.randn(y.shape).to(y.dtype)
             y.backward(g)
             st.case({'graph': 'pot_weight', 'tag': tag, 'dtype': dn}, x=w.data, g=g, y=y, scale=scale, zp=zp, dx=w.grad)
+        # Int8BiasPerTensorFixedPointInternalScaling (B/quant/fixed_point.py:78-90): a bias with a power-of-two
+        # scale of its own; a zero-initialised bias must come back as exact zeros
+        for tag in ('random', 'zero'):
+            b = torch.nn.Parameter((torch.randn(24) * 0.3).to(DT[dn]))
+            if tag == 'zero':
+                b.data.zero_()
+            q = RescalingIntQuant(
+                IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+                StatsFromParameterScaling(AbsMax(), OverTensorView(), 0, [b], PowerOfTwoRestrictValue(CeilSte()), (),
+                                          False, 1e-10),
+                PowerOfTwoIntScaling(signed=True), ZeroZeroPoint(), BitWidthConst(8))
+            y, scale, zp, bwt = q(b)
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'graph': 'pot_bias', 'tag': tag, 'dtype': dn}, x=b.data, g=g, y=y, scale=scale, zp=zp, dx=b.grad)
         # Int8ActPerTensorFixedPoint / Uint8ActPerTensorFixedPoint: percentile collected for 2 steps, then learned
         for signed in (True, False):
             q = RescalingIntQuant(

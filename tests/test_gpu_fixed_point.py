@@ -72,12 +72,34 @@ def test_pot_weight(c):
     build = Q.Int8WeightPerChannelFixedPoint if c['tag'] == 'per_channel' else Q.Int8WeightPerTensorFixedPoint
     q = build(w).to(DEV)
     y, scale, zp, bw = q(w)
-    assert _is_pot(scale)
+    # a channel whose statistic is zero takes the lower bound 1e-10 (MaxStatsScaling.scaling_min_val,
+    # B/quant/base.py:52-57) instead of a power of two, and comes back as exact zeros -- not NaN
+    live = (w.detach().reshape(w.shape[0], -1).abs().amax(1) > 0) if c['tag'].startswith('per_channel') \
+        else (w.detach().abs().amax() > 0).reshape(1)
+    assert _is_pot(scale.reshape(-1)[live.reshape(-1)])
+    assert bool(torch.isfinite(y).all())
     assert_bits(scale, c, 'scale')
     assert_bits(y, c, 'y')
     y.backward(c.torch('g', DEV))
-    channels = w.shape[0] if c['tag'] == 'per_channel' else 1
-    _dx_check(w.grad, c, channels)  # the arg-max of every channel also receives d(scale)
+    channels = w.shape[0] if c['tag'].startswith('per_channel') else 1
+    # the arg-max of every channel also receives d(scale); in an all-zero channel every element ties
+    dead = int((~live).sum()) * (w[0].numel() if c['tag'].startswith('per_channel') else w.numel())
+    _dx_check(w.grad, c, channels + dead)
+
+
+@pytest.mark.parametrize('c', [k for k in CASES if k['graph'] == 'pot_bias'],
+                         ids=lambda c: '%s-%s' % (c['tag'], c['dtype']))
+def test_pot_bias(c):
+    """Int8BiasPerTensorFixedPointInternalScaling: a zero-initialised bias gives exact zeros, as in the reference"""
+    import brevitas_amd.quant as Q
+    b = torch.nn.Parameter(c.torch('x', DEV))
+    q = Q.Int8BiasPerTensorFixedPointInternalScaling(b).to(DEV)
+    y, scale, zp, bw = q(b)
+    assert bool(torch.isfinite(y).all())
+    assert_bits(scale, c, 'scale')
+    assert_bits(y, c, 'y')
+    y.backward(c.torch('g', DEV))
+    _dx_check(b.grad, c, b.numel() if c['tag'] == 'zero' else 1)
 
 
 @pytest.mark.parametrize('dn', ['f32', 'bf16'])

@@ -223,21 +223,17 @@ def test_weight_configs_vs_oracle(nat, oracle, shape, dtype, bit_width):
 
 
 def test_full_size_one_kernel_forward(nat, act):
-    """statistic + quantizer in one launch on the [256,512,56,56] activation (teams of 32 workgroups, 16 teams
-    in flight) == the two-kernel route, bit for bit; repeated to catch a torn team hand-off"""
+    """statistic + quantizer in one launch on the [256,512,56,56] activation (the slab pipeline through the
+    Infinity Cache, the product default at this size) == the two-kernel route, bit for bit; repeated to catch
+    a torn hand-off between workgroups"""
     x, _ = act
     N, C, H, W = x.shape
     flat = x.reshape(-1)
     d = nat.QuantDesc(N, C, H * W, nat.BF16, nat.BF16, nat.BF16, nat.F32, 1, 0, -128.0, 127.0, 0, 0, 0, 0)
     stat, scale = nat.absmax_scale(flat, N, C, H * W, 1e-10, 128.0, torch.bfloat16)
     y = nat.fakequant_fwd(d, flat, scale, torch.zeros(1, device=DEV))
-    assert nat.stats_fakequant_fwd(d, flat, 1e-10, 128.0, torch.bfloat16) is None  # product default: one workgroup
-    old = nat.set_fused_max_team(64)
-    try:
-        for _ in range(5):
-            fused = nat.stats_fakequant_fwd(d, flat, 1e-10, 128.0, torch.bfloat16)
-            assert fused is not None
-            assert torch.equal(fused[0], stat) and torch.equal(fused[1], scale)
-            assert torch.equal(bits(fused[2]), bits(y))
-    finally:
-        nat.set_fused_max_team(old)
+    for _ in range(5):
+        fused = nat.stats_fakequant_fwd(d, flat, 1e-10, 128.0, torch.bfloat16)
+        assert fused is not None
+        assert torch.equal(fused[0], stat) and torch.equal(fused[1], scale)
+        assert torch.equal(bits(fused[2]), bits(y))

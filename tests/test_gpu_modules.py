@@ -348,6 +348,32 @@ def test_int_codes_emission(c):
         assert np.array_equal(codes2.cpu().numpy()[fin], codes.cpu().numpy()[fin])
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('signed', [True, False])
+def test_int_codes_emission_channels_last(dtype, signed):
+    """to_int_codes on a dense channels_last tensor with a per-channel (dim 1) scale / zero-point: the
+    column-mapped plan describes x in memory order, and the codes come back in x's logical layout --
+    equal to the codes of the contiguous tensor (pinned to the reference above) and to to_int's"""
+    m = mods()
+    torch.manual_seed(123456)
+    x = (torch.randn(3, 16, 5, 7, device=DEV) * 2).to(dtype)
+    scale = (torch.rand(1, 16, 1, 1, device=DEV) * 0.05 + 0.01).to(dtype)
+    zp = (torch.round(torch.rand(1, 16, 1, 1, device=DEV) * 20) if not signed else torch.zeros(1, 16, 1, 1, device=DEV)).to(dtype)
+    iq = m['IntQuant'](narrow_range=False, signed=signed).to(DEV)
+    bw = m['BitWidthConst'](8).to(DEV)()
+    want = iq.to_int_codes(scale, zp, bw, x)
+    xcl = x.to(memory_format=torch.channels_last)
+    assert not xcl.is_contiguous()
+    got = iq.to_int_codes(scale, zp, bw, xcl)
+    assert got.dtype == want.dtype and got.shape == x.shape
+    assert torch.equal(got, want)
+    assert torch.equal(got.to(torch.float32), iq.to_int(scale, zp, bw, xcl).to(torch.float32))
+    # per-tensor scale on the channels_last tensor (taken as one flat row in memory order)
+    s0 = torch.tensor(0.03, device=DEV).to(dtype)
+    z0 = torch.zeros((), device=DEV).to(dtype)
+    assert torch.equal(iq.to_int_codes(s0, z0, bw, xcl), iq.to_int_codes(s0, z0, bw, x))
+
+
 @pytest.mark.parametrize('kind', ['learned_scale', 'stats_scaled'])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
 def test_channels_last_activation_is_quantized_in_memory_order(kind, dtype):

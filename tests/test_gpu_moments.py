@@ -21,9 +21,14 @@ def test_moment_modules_match_reference(c):
     from brevitas_amd.core.stats import AbsAve, MeanSigmaStd
     outer, ch, inner = layout(c)
     x = c.torch('x', DEV)
-    sums = nat.abs_moments(x.reshape(-1), outer, ch, inner).double().cpu().numpy()
+    n = outer * inner
+    mean, var = moments_from_device(nat, x, outer, ch, inner)
     want_sums = O.abs_moments(c.arr('x').reshape(-1), c.dt('x'), outer, ch, inner)
-    assert np.all(np.abs(sums - want_sums) <= 1e-6 * np.abs(want_sums))
+    wmean = want_sums[:ch] / n
+    assert np.all(np.abs(mean - wmean) <= 1e-6 * np.abs(wmean))
+    if n > 1:
+        wvar = (want_sums[ch:] - want_sums[:ch] * wmean) / (n - 1)
+        assert np.all(np.abs(var - wvar) <= 1e-5 * np.abs(wvar) + 1e-12)
     mod = AbsAve(c['dim']) if c['stat'] == 'abs_ave' else MeanSigmaStd(3.0, c['dim'])
     xi = x.clone().requires_grad_(True)
     out = mod.to(DEV)(xi)
@@ -40,20 +45,60 @@ def test_moment_modules_match_reference(c):
     assert np.all(dx[c.f32('x').reshape(-1) == 0] == 0)  # sgn(0) = 0
 
 
+def moments_from_device(nat, x, outer, ch, inner):
+    """(mean |x|, unbiased var |x|) per channel from bvq_abs_moments' shifted sums, in float64"""
+    s = nat.abs_moments(x.reshape(-1), outer, ch, inner).double().cpu().numpy()
+    n = outer * inner
+    d1, d2, p = s[:ch], s[ch:2 * ch], s[2 * ch:]
+    mean = p + d1 / n
+    var = (d2 - d1 * d1 / n) / (n - 1) if n > 1 else np.full_like(mean, np.nan)
+    return mean, var
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_variance_of_a_large_offset_tensor(dtype):
+    """|x| = 100 + 0.01 randn: mean^2 / var = 10^8, where sum x^2 - (sum |x|)^2 / n of float32 sums cancels to
+    garbage; the shifted sums keep the variance (yardstick: float64 two-pass on the same values)"""
+    from brevitas_amd import _native as nat
+    from brevitas_amd.core.stats import MeanSigmaStd
+    torch.manual_seed(5)
+    x = (100.0 + 0.01 * torch.randn(6, 40, 3000, device=DEV)) * torch.where(torch.rand(6, 40, 3000, device=DEV) < 0.5, -1.0, 1.0)
+    if dtype is torch.bfloat16:
+        x = (64.0 + torch.randn(6, 40, 3000, device=DEV)).to(dtype)  # bf16 keeps 8 bits: values 62 .. 66 in steps of 0.25/0.5
+    else:
+        x = x.to(dtype)
+    a = x.double().abs()
+    for outer, ch, inner, dims in ((6, 40, 3000, (0, 2)), (1, 1, x.numel(), None)):
+        mean, var = moments_from_device(nat, x, outer, ch, inner)
+        wm = (a.mean(dim=dims) if dims else a.mean()).cpu().numpy().reshape(-1)
+        wv = (a.var(dim=dims) if dims else a.var()).cpu().numpy().reshape(-1)
+        assert np.all(np.abs(mean - wm) <= 1e-6 * wm)
+        assert np.all(np.abs(var - wv) <= 2e-4 * wv), (var, wv)
+    out = MeanSigmaStd(3.0, None).to(DEV)(x)
+    want = a.mean() + 3.0 * torch.sqrt(a.var() + 1e-8)
+    tol = 2e-6 if dtype is torch.float32 else 2.0 ** -6
+    assert abs(float(out) - float(want)) <= tol * float(want)
+    # a non-finite first element: no shift, and the statistic is what torch gives (inf / nan)
+    y = x.clone().float()
+    y.view(-1)[0] = float('inf')
+    assert np.isinf(moments_from_device(nat, y, 1, 1, y.numel())[0][0])
+
+
 def test_full_size_moments_and_learned_sigma():
     from brevitas_amd import _native as nat
     from brevitas_amd.core.stats import MeanLearnedSigmaStd
     torch.manual_seed(123456)
     x = torch.randn(64, 512, 56, 56, device=DEV, dtype=torch.bfloat16)
     n = x.numel()
-    sums = nat.abs_moments(x.reshape(-1), 1, 1, n).double()
-    ref1, ref2 = x.abs().double().sum(), (x.double() ** 2).sum()
-    assert abs(float(sums[0] - ref1)) <= 1e-6 * float(ref1) and abs(float(sums[1] - ref2)) <= 1e-6 * float(ref2)
-    pc = nat.abs_moments(x.reshape(-1), 64, 512, 56 * 56).double()
-    r1 = x.abs().double().sum(dim=(0, 2, 3))
-    assert bool(((pc[:512] - r1).abs() <= 1e-6 * r1).all())
+    sums = nat.abs_moments(x.reshape(-1), 1, 1, n)
+    mean, var = moments_from_device(nat, x, 1, 1, n)
+    a = x.double().abs()
+    assert abs(mean[0] - float(a.mean())) <= 1e-6 * float(a.mean()) and abs(var[0] - float(a.var())) <= 1e-5 * float(a.var())
+    pm, pv = moments_from_device(nat, x, 64, 512, 56 * 56)
+    r1 = a.mean(dim=(0, 2, 3)).cpu().numpy()
+    assert np.all(np.abs(pm - r1) <= 1e-6 * r1)
     # determinism
-    assert torch.equal(nat.abs_moments(x.reshape(-1), 1, 1, n), sums.float())
+    assert torch.equal(nat.abs_moments(x.reshape(-1), 1, 1, n), sums)
     # learned sigma: a parameter in the graph, state-dict key `sigma` (+ the `learned_sigma` retro key)
     m = MeanLearnedSigmaStd(2.0, (), None).to(DEV)
     xs = x[:1].float().reshape(-1).requires_grad_(True)
