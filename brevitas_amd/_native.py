@@ -37,7 +37,8 @@ EXPORTS = (
     'bvq_absmax_scale', 'bvq_running_stats_update', 'bvq_scale_from_stat', 'bvq_shard_pack', 'bvq_shard_unpack', 'bvq_abs_moments_workspace_bytes', 'bvq_abs_moments',
     'bvq_abs_affine_bwd', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_pair', 'bvq_kth_passes',
     'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd',
-    'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd_stats_workspace_bytes', 'bvq_fakequant_bwd_stats', 'bvq_fakequant_bwd')
+    'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd_stats_workspace_bytes', 'bvq_fakequant_bwd_stats', 'bvq_fakequant_bwd',
+    'bvq_learned_scale', 'bvq_fakequant_bwd_learned')
 
 
 class QuantDesc(ctypes.Structure):
@@ -103,6 +104,8 @@ def _load(path=None):
         'bvq_stat_tie_apply': (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
         'bvq_stat_tie_apply_dscale': (i32, [i32, i32, vp, vp, vp, i32, dbl, i32, vp, vp, vp, i64, i64, i64, vp]),
         'bvq_fakequant_bwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+        'bvq_learned_scale': (i32, [i32, vp, i64, dbl, i32, dbl, i32, vp, vp]),
+        'bvq_fakequant_bwd_learned': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, i32, dbl, i32, dbl, vp, vp, vp, i64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -591,6 +594,44 @@ def fakequant_bwd_stats(desc, g, x, scale, zp, stat, scale_dtype, int_threshold,
         if _timer is not None:
             _timer.after('bvq_fakequant_bwd')
     return (dx, ds) if want_dscale else dx
+
+
+def learned_scale(value, min_val, int_threshold, scale_dtype):
+    """scale = |clamp_min(value, min_val)| / int_threshold, one launch -> [value.numel()] in scale_dtype"""
+    dev = require_device(value)
+    v = value.detach().reshape(-1).contiguous()
+    scale = torch.empty(v.numel(), dtype=scale_dtype, device=dev)
+    with _DeviceGuard(dev):
+        check(lib.bvq_learned_scale(dtype_code(v.dtype), ptr(v), v.numel(), float(min_val or 0.0), int(bool(min_val)),
+                                    float(int_threshold), dtype_code(scale_dtype), ptr(scale), stream_ptr(dev)),
+              'bvq_learned_scale')
+    return scale
+
+
+def fakequant_bwd_learned(desc, g, x, scale, zp, value, min_val, int_threshold, gscale=None):
+    """quantizer backward + the learned scale's backward in its last launch -> (dx, dscale float32, dvalue flat)"""
+    dev = require_device(g, x, scale, zp, value, gscale)
+    dx = torch.empty_like(x)
+    pc = desc.scale_per_channel and desc.channels > 1
+    nsum = int(desc.channels) if pc else 1
+    v = value.detach().reshape(-1).contiguous()
+    assert v.numel() == nsum and (gscale is None or (gscale.numel() == nsum and gscale.is_contiguous()))
+    ds = torch.empty(nsum, dtype=torch.float32, device=dev)
+    dv = torch.empty(nsum, dtype=v.dtype, device=dev)
+    wsb = int(lib.bvq_fakequant_bwd_workspace_bytes(ctypes.byref(desc)))
+    if wsb < 0:
+        raise BvqError('bvq_fakequant_bwd_workspace_bytes: ' + last_error())
+    ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
+    with _DeviceGuard(dev):
+        if _timer is not None:
+            _timer.before('bvq_fakequant_bwd')
+        check(lib.bvq_fakequant_bwd_learned(ctypes.byref(desc), ptr(g), ptr(x), ptr(scale), ptr(zp), ptr(dx), ptr(ds),
+                                            ptr(v), dtype_code(v.dtype), float(min_val or 0.0), int(bool(min_val)),
+                                            float(int_threshold), ptr(gscale), ptr(dv), ptr(ws), wsb, stream_ptr(dev)),
+              'bvq_fakequant_bwd_learned')
+        if _timer is not None:
+            _timer.after('bvq_fakequant_bwd')
+    return dx, ds, dv
 
 
 def fakequant_bwd(desc, g, x, scale, zp, need_dscale, need_dzp, tie_stat=None):

@@ -166,6 +166,55 @@ class FakeQuantFn(Function):
         return dx, ds, dz, None, None, None, None, None, None, None
 
 
+class LearnedScaleFakeQuantFn(Function):
+    """scale = |clamp_min(value, min_val)| / int_threshold  ->  IntQuant with that scale and a zero zero-point:
+    the steady state of the learned-scale activation quantizers (ParameterScaling, and
+    ParameterFromRuntimeStatsScaling after its collection phase -- the default Int8ActPerTensorFloat;
+    B/core/scaling/standalone.py:75-152,155-298, B/core/quant/int.py:157-163).
+
+    Forward: one launch for the scale (instead of clamp, |.|, division), the quantizer kernel.  Backward: the
+    quantizer's backward kernel, its scale-gradient sums, and -- in the LAST reduction launch -- the chain
+    dscale -> d(threshold) -> d(value) with torch's rounding points (instead of a cast, a division, a
+    sign-multiply and their launches).  Returns (y, scale)."""
+
+    @staticmethod
+    def forward(ctx, x, value, p, min_val, thr_div, scale_dtype, qmin, qmax, round_mode, clamp_ste, pre_op):
+        ctx.set_materialize_grads(False)
+        xc, back = _memory_order(x, p.channels, p.nhwc)
+        sc = nat.learned_scale(value, min_val, thr_div, scale_dtype)
+        zp = _zero_zero_point(x.device)
+        desc = make_desc(p, xc, sc, zp.reshape(-1), qmin, qmax, round_mode, clamp_ste, nat.OUT_DEQUANT, pre_op)
+        y = nat.fakequant_fwd(desc, xc, sc, zp.reshape(-1))
+        ctx.desc, ctx.back, ctx.args = desc, back, (min_val, thr_div)
+        ctx.save_for_backward(xc, sc, zp, value)
+        if back is not None:
+            y = y.permute(back)
+        return y, sc.view(value.shape)
+
+    @staticmethod
+    def backward(ctx, gy, gscale):
+        xc, sc, zp, value = ctx.saved_tensors
+        desc = ctx.desc
+        min_val, thr_div = ctx.args
+        ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
+        if gy is None:  # only `scale` was used downstream: its own small autograd chain, no tensor pass
+            if gscale is None:
+                return (None,) * 11
+            v = value.detach()
+            if min_val:
+                v = torch.clamp_min(v, min_val)
+            sign = torch.ge(v, 0.0).to(v.dtype) - torch.lt(v, 0.0).to(v.dtype)
+            return None, (sign * (gscale.reshape(value.shape) / thr_div).to(v.dtype)), *(None,) * 9
+        gy = _like_memory_order(gy.to(ct), ctx.back)
+        gs = gscale.reshape(-1).contiguous().to(sc.dtype) if gscale is not None else None
+        dx, _, dvalue = nat.fakequant_bwd_learned(desc, gy, xc, sc, zp.reshape(-1), value, min_val, thr_div, gs)
+        if not ctx.needs_input_grad[0]:
+            dx = None
+        elif ctx.back is not None:
+            dx = dx.permute(ctx.back)
+        return dx, dvalue.view(value.shape), None, None, None, None, None, None, None, None, None
+
+
 class StatsPlan(NamedTuple):
     outer: int
     channels: int

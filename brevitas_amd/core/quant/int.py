@@ -148,6 +148,41 @@ class RescalingIntQuant(torch.nn.Module):
     def forward(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
         return self.bvq_forward_pre(x, nat.PRE_NONE)
 
+    def _learned_scale_args(self, x: Tensor, bit_width: Tensor):
+        """(value, min_val, Plan, thr_div, scale_dtype, qmin, qmax, round_mode, clamp_ste) if the scale is a learned
+        parameter with a float restriction right now -- scale = |clamp_min(value)| / int_threshold -- and the fused
+        quantizer kernel covers the operands; else None"""
+        if not config.FUSED_PATHS or not x.is_cuda:
+            return None
+        bw = getattr(bit_width, 'bvq_host_value', None)
+        iq, sc = self.int_quant, self.scaling_impl
+        if bw is None or type(iq) is not IntQuant or not isinstance(iq.delay_wrapper.delay_impl, _NoDelay):
+            return None
+        round_mode = getattr(iq.float_to_int_impl, 'bvq_round_mode', None)
+        clamp_ste = getattr(iq.tensor_clamp_impl, 'bvq_clamp_ste', None)
+        if round_mode is None or clamp_ste is None:
+            return None
+        if type(self.zero_point_impl) is not ZeroZeroPoint or type(self.int_scaling_impl) is not IntScaling:
+            return None
+        learned = getattr(sc, 'bvq_learned_scale', None)
+        found = learned() if learned is not None else None
+        if found is None:
+            return None
+        value, min_val = found
+        if not value.is_cuda or value.dtype not in _fused._FLOATS or value.numel() < 1:
+            return None
+        zp = _fused._zero_zero_point(x.device)
+        p = _fused.plan(x, value, zp)
+        if p is None or p.zp_pc:
+            return None
+        int_thr = self.int_scaling_impl.host_value(bw)
+        if value.dim() > 0:  # a dimensioned threshold keeps its dtype: the 0-dim float32 int_threshold is converted
+            scale_dtype, thr_div = value.dtype, _fused._as_dtype_value(int_thr, value.dtype)
+        else:
+            scale_dtype, thr_div = torch.promote_types(value.dtype, torch.float32), int_thr
+        qmin, qmax = int_range_host(iq.signed, iq.narrow_range, bw)
+        return value, min_val, p, thr_div, scale_dtype, qmin, qmax, round_mode, clamp_ste
+
     def _scale_ignores_input(self) -> bool:
         """True if scaling_impl(x) does not read x right now (learned / constant / frozen statistics)"""
         sc = self.scaling_impl
@@ -212,6 +247,15 @@ class RescalingIntQuant(torch.nn.Module):
                 pre_op)
             if runtime is not None:
                 runtime.update_running_stats(stat)
+            zero_point = self.zero_point_impl(x, scale, bit_width)
+            return y, scale, zero_point, bit_width
+        learned = self._learned_scale_args(x, bit_width)
+        if learned is not None:
+            # learned scale (steady state of the default activation quantizers): one launch for the scale, the
+            # quantizer kernel; in backward the scale's own chain rides on the last reduction launch
+            value, min_val, p, thr_div, scale_dtype, qmin, qmax, round_mode, clamp_ste = learned
+            y, scale = _fused.LearnedScaleFakeQuantFn.apply(x, value, p, min_val, thr_div, scale_dtype, qmin, qmax,
+                                                            round_mode, clamp_ste, pre_op)
             zero_point = self.zero_point_impl(x, scale, bit_width)
             return y, scale, zero_point, bit_width
         # generic orchestration (B/core/quant/int.py:157-163)

@@ -44,6 +44,11 @@ def _as_parameter_init(init: Union[float, Tensor], shape, what: str) -> Tensor:
     return torch.tensor(init)
 
 
+def _is_float_restriction(m) -> bool:
+    from brevitas_amd.core.restrict_val import FloatRestrictValue
+    return type(m) in (Identity, FloatRestrictValue)
+
+
 class ParameterScaling(TolerantLoad, torch.nn.Module):
     """learned threshold |clamp_min(restrict(value))| (B/core/scaling/standalone.py:75-152)"""
 
@@ -62,6 +67,14 @@ class ParameterScaling(TolerantLoad, torch.nn.Module):
 
     def forward(self, placeholder: Tensor) -> Tensor:
         return abs_binary_sign_grad(self.restrict_clamp_scaling(self.value))
+
+    def bvq_learned_scale(self):
+        """(value, min_val) if the threshold is exactly |clamp_min_ste(value, min_val)| (float restriction): the form
+        RescalingIntQuant folds into one launch; else None"""
+        rc = self.restrict_clamp_scaling
+        if not _is_float_restriction(rc.restrict_value_impl):
+            return None
+        return self.value, getattr(rc.clamp_min_ste, 'min_val', None)
 
     def _load_from_state_dict(self, state_dict, prefix, *hook_args):
         legacy = prefix + 'learned_value'  # the parameter's name in old checkpoints
@@ -117,3 +130,10 @@ class ParameterFromRuntimeStatsScaling(CollectThenLearn, torch.nn.Module):
             return self.training_forward(stats_input)
         frozen = self.bvq_collected() if self.counter <= self.collect_stats_steps else self.value
         return self._learned(frozen)
+
+    def bvq_learned_scale(self):
+        """(value, min_val) once the collection phase is over and the threshold is |clamp_min_ste(value)| (float
+        restriction); None while statistics are still collected or handed over"""
+        if self.counter <= self.collect_stats_steps or not _is_float_restriction(self.restrict_scaling.restrict_value_impl):
+            return None
+        return self.value, getattr(self.clamp_scaling, 'min_val', None)

@@ -210,6 +210,7 @@ struct Tiling {
   int64_t units;      // nob * channels * ppr
   int32_t channels;
   int32_t rpu;        // rows (outer indices) per unit
+  int32_t reverse;    // walk the units from the tensor's end to its start (cache-reuse experiments; 0 by default)
 };
 
 // elements one wave handles per piece, in 16-byte chunks per lane.  8 chunks = 8 KiB (2-byte types).
@@ -271,8 +272,9 @@ struct Unit {
 __device__ __forceinline__ Unit locate_unit(const Tiling& t) {
   Unit u;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  u.id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  u.valid = u.id < t.units;
+  const int64_t slot = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  u.valid = slot < t.units;
+  u.id = t.reverse ? t.units - 1 - slot : slot;  // the unit's id (slot of its partials) stays its position in memory
   if (!u.valid) {
     u.base = u.row_stride = u.len = u.pos0 = 0;
     u.nrows = u.channel = 0;

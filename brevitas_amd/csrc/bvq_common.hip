@@ -157,6 +157,7 @@ Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, in
   const int64_t quantum = (int64_t)kWave * vec;  // one 16-byte load per lane
   int64_t piece = (int64_t)default_piece_chunks() * quantum;
   t.rpu = 1;
+  t.reverse = 0;
   if (row_len >= piece) {
     // long rows: cut them into default-sized pieces (a per-tensor quantizer is one very long row: ~10^5
     // units, whose partials the finish kernels combine in two stages), bounded by unit_cap per channel.
@@ -187,7 +188,10 @@ Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, in
           best_eff = eff;
           best = r;
         }
-        if (few_rows && eff >= 0.86) break;
+#ifndef BVQ_FEW_ROWS_EFF
+#define BVQ_FEW_ROWS_EFF 0.86
+#endif
+        if (few_rows && eff >= BVQ_FEW_ROWS_EFF) break;
       }
       t.rpu = (int32_t)best;
     }

@@ -39,8 +39,11 @@ struct QuantArgs {
 #ifndef BVQ_FWD_UNROLL
 #define BVQ_FWD_UNROLL 8
 #endif
+#ifndef BVQ_BWD_WAVES
+#define BVQ_BWD_WAVES 4  // occupancy floor handed to the register allocator (waves per SIMD)
+#endif
 #ifndef BVQ_BWD_DEPTH
-#define BVQ_BWD_DEPTH 2
+#define BVQ_BWD_DEPTH 4
 #endif
 constexpr int kUnroll = BVQ_FWD_UNROLL;   // forward: 16-byte loads of x in flight per lane before arithmetic
 constexpr int kBwdDepth = BVQ_BWD_DEPTH;  // backward: chunks of each input stream (x, g) prefetched ahead of the arithmetic
@@ -357,7 +360,7 @@ __device__ __forceinline__ void fwd_unit(const QuantArgs& a, const Unit& u, cons
   }
 }
 
-template <typename XT, typename CT, int VEC, int RM, bool NT>
+template <typename XT, typename CT, int VEC, int RM, bool NT, bool NTL = NT>
 __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
   const Unit u = locate_unit(a.t);
   if (!u.valid) return;
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
   // wave-uniform choices: fused pre-activation, zero zero-point (16-bit compute types: saves two
   // re-roundings per element), and (bf16) the reciprocal fast path
   const bool zp0 = sizeof(CT) == 2 && zp_is_pos_zero(z);
-#define BVQ_FWD_UNIT(ZP0, PRE, DIV) fwd_unit<XT, CT, VEC, RM, NT, ZP0, PRE>(a, u, DIV, s, z, qmin, qmax)
+#define BVQ_FWD_UNIT(ZP0, PRE, DIV) fwd_unit<XT, CT, VEC, RM, NT, ZP0, PRE, NTL>(a, u, DIV, s, z, qmin, qmax)
 #define BVQ_FWD_PRE(ZP0, DIV)      \
   do {                             \
     if (a.pre_relu)                \
@@ -475,7 +478,10 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_cols_kernel(ColsQuantArg
 // channel at a time: every wave loads one slice of the channel (<= 8 chunks of 16 bytes per lane: 8 KiB
 // per wave) into registers, the workgroup agrees on the channel's maximum through LDS, and every wave
 // quantizes what it still holds.  x is read ONCE, one launch instead of three.  Channels that do not fit
-// one workgroup's registers take the pipelined kernel below or the two-kernel route.
+// one workgroup's registers take the two-kernel route: holding them across several workgroups (round 1) or
+// pipelining slabs of channels through the Infinity Cache in one launch (round 2,
+// profiles/r02_slab_pipeline_experiment.txt) both lost to it -- the hand-off between workgroups costs more
+// than the saved read.
 constexpr int kFusedSlots = 8;          // 16-byte chunks per lane held in registers
 constexpr int kFusedSliceChunks = 512;  // kWave * kFusedSlots
 constexpr int kFusedMaxWaves = 8;       // waves per workgroup
@@ -629,183 +635,6 @@ __global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// statistic + quantizer in ONE launch, large per-channel tensors: a slab pipeline through the Infinity Cache
-// ------------------------------------------------------------------------------------------------
-// A [N,C,H,W] activation far larger than the 256 MiB Infinity Cache (MALL) costs the two-kernel forward three
-// HBM passes: the statistic reads x, the quantizer reads it again and writes y.  A channel's statistic
-// depends on that channel alone, so the tensor is cut into SLABS of `cps` consecutive channels (a few MB to
-// a few tens of MB) and ONE grid walks them as a software pipeline: the workgroups of "phase" p hold the
-// statistic units (S) of slab p interleaved with the quantizer units (Q) of slab p - lag.  Workgroups are
-// dispatched in index order, so while slab p streams in from HBM, slab p - lag -- whose statistic finished
-// long ago, and whose bytes still sit in the Infinity Cache -- is quantized: its second read of x is served
-// on-die, and HBM sees one read of x and one write of y.
-//
-// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility; agent-scope atomics both sides): an S wave folds
-// its maximum into stat_bits[channel] (atomic max), waits for it (s_waitcnt vmcnt(0)) and adds 1 to its
-// slab's arrival counter (sharded over kPipeShards words); a Q wave polls the counters of ITS slab (relaxed
-// agent-scope loads), then reads the channel's key.  A Q wave waits only for S units that were dispatched
-// `lag` phases earlier and never wait themselves, so the wait is short by construction; it does not DEPEND on
-// the dispatch order either: after kPipeSpinLimit polls a Q wave computes its channel's statistic itself
-// from x (slow, correct), so the kernel finishes under any placement, order or residency.
-constexpr int kPipeShards = 16;
-constexpr int kPipeSpinLimit = 4096;
-
-struct PipeArgs {
-  QuantArgs q;          // x, y, qmin/qmax, round_mode, pre_relu (t / scale / zp unused)
-  void* stat_out;       // [channels], dtype of x
-  void* scale_out;      // [channels], scale_dtype
-  uint32_t* stat_bits;  // workspace, zeroed: per-channel running maximum of the |x| keys
-  uint32_t* done;       // workspace, zeroed: [nslab][kPipeShards] finished S units
-  int64_t outer, inner;
-  int32_t channels, cps, nslab, lag;
-  int32_t rpu_s, nob_s;  // rows (outer indices) per S unit, S units per channel
-  int32_t rpu_q, nob_q;  // the same for Q units
-  int32_t bs, bq;        // workgroups per slab of each kind
-  float min_val, int_threshold;
-  int32_t use_min;
-  int32_t spin_limit;    // polls before a Q wave computes the statistic itself (< 0: at once; test hook)
-};
-
-// max |x| key over a unit (the loop of absmax_kernel, bvq_stats.hip)
-template <typename T, int VEC, bool NT, bool RELU>
-__device__ __forceinline__ uint32_t absmax_unit(const T* __restrict__ xp, const Unit& u, int lane) {
-  constexpr int kU = 8;
-  uint32_t m = 0;
-  ChunkWalker cur;
-  cur.init(u, VEC, lane);
-  const int64_t total = (int64_t)u.nrows * cur.cpr;
-  for (int64_t done = 0; done < total; done += (int64_t)kWave * kU) {
-    vec_t<T, VEC> xv[kU];
-    bool ok[kU];
-#pragma unroll
-    for (int j = 0; j < kU; ++j) {
-      ok[j] = cur.valid();
-      if (ok[j]) xv[j] = load_vec<T, VEC, NT>(xp + cur.offset(u.row_stride, VEC));
-      cur.next();
-    }
-#pragma unroll
-    for (int j = 0; j < kU; ++j) {
-      if (ok[j]) {
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-          const uint32_t b = pre_abs_bits<T, RELU>(xv[j].v[k]);
-          m = b > m ? b : m;
-        }
-      }
-    }
-  }
-  return wave_max_u32(m);
-}
-
-template <typename T, int RM, bool SNT, bool QNTL, bool QNTS>
-__global__ __launch_bounds__(kBlock) void pipe_absmax_fakequant_kernel(PipeArgs a) {
-  constexpr int VEC = elem<T>::vec;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int32_t per_phase = a.bs + a.bq;
-  const int32_t phase = (int32_t)(blockIdx.x / (uint32_t)per_phase);
-  const int32_t r = (int32_t)(blockIdx.x - (uint32_t)phase * (uint32_t)per_phase);
-  // the bs S workgroups of a phase are spread evenly among its bq Q workgroups (position rr is an S workgroup
-  // when floor(rr bs / per_phase) steps there); the pattern is rotated from phase to phase so that an integer
-  // spacing does not pin the S workgroups to the same XCDs (workgroup b runs on XCD b % 8)
-  const int32_t rr = (int32_t)(((int64_t)r + 3 * (int64_t)phase) % per_phase);
-  const int32_t sb = (int32_t)(((int64_t)rr * a.bs) / per_phase);
-  const bool is_s = (int32_t)(((int64_t)(rr + 1) * a.bs) / per_phase) > sb;
-  const int32_t idx = is_s ? sb : rr - sb;
-  const int32_t slab = is_s ? phase : phase - a.lag;
-  if (slab < 0 || slab >= a.nslab) return;
-  const int32_t c0 = slab * a.cps;
-  const int32_t cnt = a.channels - c0 < a.cps ? a.channels - c0 : a.cps;  // channels of this slab
-  const int32_t unit = idx * kWavesPerBlock + wave;
-  const T* __restrict__ xbase = reinterpret_cast<const T*>(a.q.x);
-  Unit u;
-  u.valid = true;
-  u.row_stride = (int64_t)a.channels * a.inner;
-  u.len = a.inner;
-  u.id = 0;
-
-  if (is_s) {
-    if (unit >= a.nob_s * cnt) return;
-    const int32_t ob = unit / cnt, cl = unit - ob * cnt;  // channel fastest: neighbouring waves, neighbouring memory
-    const int64_t o0 = (int64_t)ob * a.rpu_s;
-    u.channel = c0 + cl;
-    u.nrows = (int32_t)(a.outer - o0 < a.rpu_s ? a.outer - o0 : a.rpu_s);
-    u.base = (o0 * a.channels + u.channel) * a.inner;
-    u.pos0 = o0 * a.inner;
-    const uint32_t m = a.q.pre_relu ? absmax_unit<T, VEC, SNT, true>(xbase + u.base, u, lane)
-                                    : absmax_unit<T, VEC, SNT, false>(xbase + u.base, u, lane);
-    if (lane == 0) {
-      // a RETURNING atomic: its old value comes back only once the maximum is in place, so the arrival
-      // below cannot overtake it
-      const uint32_t old = __hip_atomic_fetch_max(&a.stat_bits[u.channel], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
-      __hip_atomic_fetch_add(&a.done[slab * kPipeShards + (int)(blockIdx.x % kPipeShards)], 1u, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
-  }
-
-  if (unit >= a.nob_q * cnt) return;
-  const int32_t ob = unit / cnt, cl = unit - ob * cnt;
-  const int64_t o0 = (int64_t)ob * a.rpu_q;
-  u.channel = c0 + cl;
-  u.nrows = (int32_t)(a.outer - o0 < a.rpu_q ? a.outer - o0 : a.rpu_q);
-  u.base = (o0 * a.channels + u.channel) * a.inner;
-  u.pos0 = o0 * a.inner;
-  // wait until every S unit of the slab has arrived
-  const uint32_t expected = (uint32_t)(a.nob_s * cnt);
-  uint32_t key;
-  {
-    int spins = 0;
-    bool ready = false;
-    while (a.spin_limit >= 0) {
-      uint32_t v = lane < kPipeShards
-                       ? __hip_atomic_load(&a.done[slab * kPipeShards + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                       : 0u;
-#pragma unroll
-      for (int off = kPipeShards / 2; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, kWave);
-      ready = __builtin_amdgcn_readfirstlane((int)v) == (int)expected;
-      if (ready || ++spins > a.spin_limit) break;
-      __builtin_amdgcn_s_sleep(16);
-    }
-    if (ready) {
-      key = __hip_atomic_load(&a.stat_bits[u.channel], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      // never observed; keeps the kernel independent of dispatch order and residency: the channel's
-      // statistic from x itself
-      Unit w = u;
-      w.nrows = (int32_t)a.outer;
-      w.base = (int64_t)u.channel * a.inner;
-      key = a.q.pre_relu ? absmax_unit<T, VEC, false, true>(xbase + w.base, w, lane)
-                         : absmax_unit<T, VEC, false, false>(xbase + w.base, w, lane);
-    }
-    key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
-  }
-  float stat;
-  const float s = scale_from_key<T>(key, a.use_min, a.min_val, a.int_threshold, a.q.scale_dtype, stat);
-  if (ob == 0 && lane == 0) store_stat_scale<T>(a.stat_out, a.scale_out, a.q.scale_dtype, u.channel, stat, s);
-  const float qmin = rnd<T>(a.q.qmin), qmax = rnd<T>(a.q.qmax);
-  constexpr bool ZP0 = sizeof(T) == 2;
-#define BVQ_PIPE_UNIT(PRE, DIV) fwd_unit<T, T, VEC, RM, QNTS, ZP0, PRE, QNTL>(a.q, u, DIV, s, 0.f, qmin, qmax)
-  if constexpr (elem<T>::id == BVQ_BF16) {
-    if (bf16_scale_ok(s)) {
-      const DivBf16 div{1.0f / s};
-      if (a.q.pre_relu)
-        BVQ_PIPE_UNIT(true, div);
-      else
-        BVQ_PIPE_UNIT(false, div);
-      return;
-    }
-  }
-  const DivExact div{s};
-  if (a.q.pre_relu)
-    BVQ_PIPE_UNIT(true, div);
-  else
-    BVQ_PIPE_UNIT(false, div);
-#undef BVQ_PIPE_UNIT
-}
-
 #endif  // forward part
 
 #if BVQ_PART == 0 || BVQ_PART == 2
@@ -867,6 +696,9 @@ __device__ __forceinline__ f2 bwd_elem2(f2 xf, f2 gf, const Div& div, S s, S z, 
   const f2 dxv = SAME16 ? div(dt) : rnd2<CT>(div(dt));
   if constexpr (MODE >= kBwdDs) {
     const f2 t5 = ZP0 ? t4 : rnd2<CT>(t4 - z);
+    // (every product rounded to CT like the reference's ops.  Keeping the two terms in float32 would save three
+    //  roundings per element, but the compiler then holds 25 more registers live -- 117 instead of 92 at depth 4,
+    //  one wave per SIMD less -- and the kernel is no faster: profiles/r02_backward_variants.txt)
     const f2 term1 = rnd2<CT>(gf * t5);
     const f2 term2 = rnd2<CT>(-dt * rnd2<CT>(div(t1)));
     ds_acc += term1;
@@ -876,7 +708,8 @@ __device__ __forceinline__ f2 bwd_elem2(f2 xf, f2 gf, const Div& div, S s, S z, 
   return dxv;
 }
 
-template <typename XT, typename CT, int VEC, int RM, int MODE, bool NT, bool ZP0, bool PRE, typename Div>
+// NT: cache policy of the loads of g and the stores of dx; NTX: of the loads of x (the same unless stated)
+template <typename XT, typename CT, int VEC, int RM, int MODE, bool NT, bool ZP0, bool PRE, bool NTX = NT, typename Div>
 __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, const Div& div, float s,
                                          float z, float qmin, float qmax) {
   const int lane = threadIdx.x & 63;
@@ -916,7 +749,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
     offb[j] = cur.offset(u.row_stride, VEC);
     if (j < steps) {  // wave-uniform
       const int64_t lo = okb[j] ? offb[j] : 0;  // past the end: re-read the unit's first chunk
-      xb[j] = load_vec<XT, VEC, NT>(xp + lo);
+      xb[j] = load_vec<XT, VEC, NTX>(xp + lo);
       gb[j] = load_vec<CT, VEC, NT>(gp + lo);
     }
     cur.next();
@@ -934,7 +767,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
       offb[j] = cur.offset(u.row_stride, VEC);
       if (base + j + kD < steps) {
         const int64_t lo = okb[j] ? offb[j] : 0;
-        xb[j] = load_vec<XT, VEC, NT>(xp + lo);
+        xb[j] = load_vec<XT, VEC, NTX>(xp + lo);
         gb[j] = load_vec<CT, VEC, NT>(gp + lo);
       }
       cur.next();
@@ -1051,15 +884,15 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
 }
 
 // (96 scalar registers: one more would cost a resident workgroup per CU -- MI355X_MICROARCH.md, Residency)
-template <typename XT, typename CT, int VEC, int RM, int MODE, bool NT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void fakequant_bwd_kernel(QuantArgs a) {
+template <typename XT, typename CT, int VEC, int RM, int MODE, bool NT, bool NTX = NT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(BVQ_BWD_WAVES, 8))) void fakequant_bwd_kernel(QuantArgs a) {
   const Unit u = locate_unit(a.t);
   if (!u.valid) return;
   float s, z;
   load_scale_zp<CT>(a, u.channel, s, z);
   const float qmin = rnd<CT>(a.qmin), qmax = rnd<CT>(a.qmax);
   const bool zp0 = sizeof(CT) == 2 && zp_is_pos_zero(z);
-#define BVQ_BWD_UNIT(ZP0, PRE, DIV) bwd_unit<XT, CT, VEC, RM, MODE, NT, ZP0, PRE>(a, u, DIV, s, z, qmin, qmax)
+#define BVQ_BWD_UNIT(ZP0, PRE, DIV) bwd_unit<XT, CT, VEC, RM, MODE, NT, ZP0, PRE, NTX>(a, u, DIV, s, z, qmin, qmax)
 #define BVQ_BWD_PRE(ZP0, DIV)      \
   do {                             \
     if (a.pre_relu)                \
@@ -1433,6 +1266,17 @@ static void launch_fwd(const QuantArgs& a, int vec, bool nt, hipStream_t st) {
   constexpr int V = elem<XT>::vec;
   const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
   const bool rne = a.round_mode == BVQ_ROUND;
+#ifdef BVQ_CACHE_EXPERIMENT
+  // developer build: cache policy of the x loads (BVQ_X_FWD_NTL) and the y stores (BVQ_X_FWD_NTS) chosen per call
+  if (vec == V && rne && getenv("BVQ_X_FWD_NTL")) {
+    const int l = atoi(getenv("BVQ_X_FWD_NTL")), w = getenv("BVQ_X_FWD_NTS") ? atoi(getenv("BVQ_X_FWD_NTS")) : 1;
+    if (w && l) fakequant_fwd_kernel<XT, CT, V, BVQ_ROUND, true, true><<<grid, block, 0, st>>>(a);
+    else if (w) fakequant_fwd_kernel<XT, CT, V, BVQ_ROUND, true, false><<<grid, block, 0, st>>>(a);
+    else if (l) fakequant_fwd_kernel<XT, CT, V, BVQ_ROUND, false, true><<<grid, block, 0, st>>>(a);
+    else fakequant_fwd_kernel<XT, CT, V, BVQ_ROUND, false, false><<<grid, block, 0, st>>>(a);
+    return;
+  }
+#endif
   if (vec == V) {
     if (rne && nt)
       fakequant_fwd_kernel<XT, CT, V, BVQ_ROUND, true><<<grid, block, 0, st>>>(a);
@@ -1458,6 +1302,17 @@ static void launch_bwd_mode(const QuantArgs& a, int vec, bool nt, hipStream_t st
   constexpr int V = elem<XT>::vec;
   const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
   const bool rne = a.round_mode == BVQ_ROUND;
+#ifdef BVQ_CACHE_EXPERIMENT
+  // developer build: cache policy of the x loads (BVQ_X_BWD_NTX) and of the g loads / dx stores (BVQ_X_BWD_NT)
+  if (vec == V && rne && getenv("BVQ_X_BWD_NTX")) {
+    const int xl = atoi(getenv("BVQ_X_BWD_NTX")), o = getenv("BVQ_X_BWD_NT") ? atoi(getenv("BVQ_X_BWD_NT")) : 1;
+    if (o && xl) fakequant_bwd_kernel<XT, CT, V, BVQ_ROUND, MODE, true, true><<<grid, block, 0, st>>>(a);
+    else if (o) fakequant_bwd_kernel<XT, CT, V, BVQ_ROUND, MODE, true, false><<<grid, block, 0, st>>>(a);
+    else if (xl) fakequant_bwd_kernel<XT, CT, V, BVQ_ROUND, MODE, false, true><<<grid, block, 0, st>>>(a);
+    else fakequant_bwd_kernel<XT, CT, V, BVQ_ROUND, MODE, false, false><<<grid, block, 0, st>>>(a);
+    return;
+  }
+#endif
   if (vec == V) {
     if (rne && nt)
       fakequant_bwd_kernel<XT, CT, V, BVQ_ROUND, MODE, true><<<grid, block, 0, st>>>(a);
@@ -1549,6 +1404,9 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
   const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3, true), full);
   QuantArgs a = {};
   a.t = make_tiling(outer, channels, row_len, vec, 0, true);
+#ifdef BVQ_CACHE_EXPERIMENT
+  if (getenv("BVQ_X_FWD_REV")) a.t.reverse = atoi(getenv("BVQ_X_FWD_REV"));
+#endif
   a.x = x;
   a.scale = scale;
   a.zp = zp;
@@ -1622,119 +1480,11 @@ static bool fused_plan(const bvq_quant_desc* d, const void* x, const void* y, Fu
   return true;
 }
 
-// the slab pipeline applies to per-channel tensors too large for the Infinity Cache to serve the
-// two-kernel route's second read of x
-struct PipePlan {
-  int32_t cps, nslab, lag, rpu_s, nob_s, rpu_q, nob_q, bs, bq;
-  int snt, qntl, qnts;
-  int64_t lds_bytes;
-};
-
-static int64_t env_i64(const char* name, int64_t dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoll(v) : dflt;
-}
-
-static bool pipe_plan(const bvq_quant_desc* d, const void* x, const void* y, PipePlan& p) {
-  const FusedShape f = fused_shape(d, x, y);
-  if (!f.ok || f.channels < 2) return false;
-  if (!env_i64("BVQ_PIPE", 1)) return false;
-  const int es = dtype_size(d->x_dtype);
-  const int64_t row_bytes = f.inner * es;
-  const int64_t chan_bytes = f.outer * row_bytes;
-  const int64_t total = chan_bytes * f.channels;
-  // rows long enough for the row-mapped units, a tensor that does not fit the cache next to its output
-  if (row_bytes < 1024 || f.inner > (1 << 24) || f.outer > (1 << 20)) return false;
-  if (total < env_i64("BVQ_PIPE_MIN_MB", 192) * (1ll << 20)) return false;
-  const int64_t slab_bytes = env_i64("BVQ_PIPE_SLAB_KB", 12 * 1024) * 1024;
-  const int64_t lag_bytes = env_i64("BVQ_PIPE_LAG_KB", 96 * 1024) * 1024;
-  int64_t cps = slab_bytes / chan_bytes;
-  if (cps < 1) cps = 1;
-  if (cps > f.channels) cps = f.channels;
-  if (cps * chan_bytes > 64ll << 20) return false;  // one channel alone outgrows the cache window
-  const int64_t nslab = (f.channels + cps - 1) / cps;
-  int64_t lag = (lag_bytes + cps * chan_bytes - 1) / (cps * chan_bytes);
-  if (lag < 1) lag = 1;
-  if (nslab < 2 * lag + 2) return false;  // too few slabs for the pipeline to pay
-  const int64_t cpr = f.inner / f.vec;
-  // rows per unit: the statistic takes ~16 KiB per wave, the quantizer the fewest rows that keep >= 86 % of
-  // the lanes of its 64-wide accesses busy (make_tiling's rules)
-  int64_t rpu_s = env_i64("BVQ_PIPE_RPU_S", 0);
-  if (rpu_s <= 0) {
-    rpu_s = (16384 + row_bytes - 1) / row_bytes;
-    if (rpu_s < 1) rpu_s = 1;
-  }
-  if (rpu_s > f.outer) rpu_s = f.outer;
-  int64_t rpu_q = 1;
-  for (int64_t r = 1; r <= f.outer && r <= 64; ++r) {
-    const int64_t loads = (r * cpr + kWave - 1) / kWave;
-    rpu_q = r;
-    if ((double)(r * cpr) / (double)(loads * kWave) >= 0.86) break;
-  }
-  if (cpr >= kWave) rpu_q = 1;
-  const int64_t nob_s = (f.outer + rpu_s - 1) / rpu_s, nob_q = (f.outer + rpu_q - 1) / rpu_q;
-  const int64_t bs = (nob_s * cps + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int64_t bq = (nob_q * cps + kWavesPerBlock - 1) / kWavesPerBlock;
-  if ((nslab + lag) * (bs + bq) >= (1ll << 31)) return false;
-  p.cps = (int32_t)cps;
-  p.nslab = (int32_t)nslab;
-  p.lag = (int32_t)lag;
-  p.rpu_s = (int32_t)rpu_s;
-  p.nob_s = (int32_t)nob_s;
-  p.rpu_q = (int32_t)rpu_q;
-  p.nob_q = (int32_t)nob_q;
-  p.bs = (int32_t)bs;
-  p.bq = (int32_t)bq;
-  p.snt = (int)env_i64("BVQ_PIPE_SNT", 0);
-  p.qntl = (int)env_i64("BVQ_PIPE_QNTL", 1);
-  p.qnts = (int)env_i64("BVQ_PIPE_QNTS", 1);
-  p.lds_bytes = env_i64("BVQ_PIPE_LDS_KB", 0) * 1024;
-  if (p.lds_bytes < 0 || p.lds_bytes > 64 * 1024) p.lds_bytes = 0;  // above 64 KiB needs an opt-in attribute
-  return true;
-}
-
-static int64_t pipe_workspace_words(const PipePlan& p, int64_t channels) {
-  return channels + (int64_t)p.nslab * kPipeShards + 4;
-}
-
 extern "C" int64_t bvq_stats_fakequant_fwd_workspace_bytes(const bvq_quant_desc* d, const void* x, const void* y) {
   if (validate(d)) return -1;
   FusedPlan p;
   if (fused_plan(d, x, y, p)) return 16;  // no workspace needed; non-zero says "covered"
-  PipePlan pp;
-  if (pipe_plan(d, x, y, pp)) return pipe_workspace_words(pp, d->channels) * (int64_t)sizeof(uint32_t);
   return 0;  // not applicable: use bvq_absmax_scale + bvq_fakequant_fwd
-}
-
-template <typename T>
-static void launch_pipe(const PipeArgs& a, const PipePlan& p, bool rne, hipStream_t st) {
-  const dim3 grid((unsigned)((int64_t)(p.nslab + p.lag) * (p.bs + p.bq))), block(kBlock);
-  // unused dynamic LDS caps the resident workgroups per CU (160 KiB / lds): fewer waves in flight means a
-  // statistic unit finishes sooner after its dispatch, so a shorter lag keeps the slab inside the cache
-  const size_t lds = (size_t)p.lds_bytes;
-#define BVQ_PIPE_RM(SNT, QNTL, QNTS)                                                            \
-  do {                                                                                          \
-    if (rne)                                                                                    \
-      pipe_absmax_fakequant_kernel<T, BVQ_ROUND, SNT, QNTL, QNTS><<<grid, block, lds, st>>>(a); \
-    else                                                                                        \
-      pipe_absmax_fakequant_kernel<T, kAnyRM, SNT, QNTL, QNTS><<<grid, block, lds, st>>>(a);    \
-  } while (0)
-#ifdef BVQ_PIPE_EXPERIMENT
-  const int v = (p.snt ? 4 : 0) | (p.qntl ? 2 : 0) | (p.qnts ? 1 : 0);
-  switch (v) {
-    case 0: BVQ_PIPE_RM(false, false, false); break;
-    case 1: BVQ_PIPE_RM(false, false, true); break;
-    case 2: BVQ_PIPE_RM(false, true, false); break;
-    case 3: BVQ_PIPE_RM(false, true, true); break;
-    case 4: BVQ_PIPE_RM(true, false, false); break;
-    case 5: BVQ_PIPE_RM(true, false, true); break;
-    case 6: BVQ_PIPE_RM(true, true, false); break;
-    default: BVQ_PIPE_RM(true, true, true); break;
-  }
-#else
-  BVQ_PIPE_RM(false, true, true);
-#endif
-#undef BVQ_PIPE_RM
 }
 
 extern "C" int bvq_stats_fakequant_fwd(const bvq_quant_desc* d, const void* x, double min_val, int use_min,
@@ -1751,7 +1501,6 @@ extern "C" int bvq_stats_fakequant_fwd(const bvq_quant_desc* d, const void* x, d
   const int64_t channels = pc ? d->channels : 1;
   const bool rne = d->round_mode == BVQ_ROUND;
   FusedPlan p;
-  PipePlan pp;
   if (fused_plan(d, x, y, p)) {
     FusedArgs a = {};
     a.x = x;
@@ -1791,48 +1540,8 @@ extern "C" int bvq_stats_fakequant_fwd(const bvq_quant_desc* d, const void* x, d
 #undef BVQ_FUSED
     return check_launch("bvq_stats_fakequant_fwd");
   }
-  if (!pipe_plan(d, x, y, pp)) {
-    set_error("bvq_stats_fakequant_fwd: shape / layout not covered by the one-launch forms");
-    return BVQ_ERR_UNSUPPORTED;
-  }
-  const int64_t words = pipe_workspace_words(pp, channels);
-  if (workspace_bytes < words * (int64_t)sizeof(uint32_t)) {
-    set_error("bvq_stats_fakequant_fwd: workspace too small");
-    return BVQ_ERR_WORKSPACE;
-  }
-  PipeArgs a = {};
-  a.q.x = x;
-  a.q.y = y;
-  fill_args(a.q, d);
-  a.q.out_int = 0;
-  a.stat_out = stat_out;
-  a.scale_out = scale_out;
-  a.stat_bits = reinterpret_cast<uint32_t*>(workspace);
-  a.done = a.stat_bits + channels;
-  a.outer = d->outer;
-  a.inner = d->inner;
-  a.channels = (int32_t)channels;
-  a.cps = pp.cps;
-  a.nslab = pp.nslab;
-  a.lag = pp.lag;
-  a.rpu_s = pp.rpu_s;
-  a.nob_s = pp.nob_s;
-  a.rpu_q = pp.rpu_q;
-  a.nob_q = pp.nob_q;
-  a.bs = pp.bs;
-  a.bq = pp.bq;
-  a.min_val = round_host((float)min_val, d->x_dtype);
-  a.int_threshold = (float)int_threshold;
-  a.use_min = use_min;
-  a.spin_limit = (int32_t)env_i64("BVQ_PIPE_SPIN_LIMIT", kPipeSpinLimit);
-  fused_zero_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(a.stat_bits, words);
-  if (d->x_dtype == BVQ_F32)
-    launch_pipe<float>(a, pp, rne, st);
-  else if (d->x_dtype == BVQ_BF16)
-    launch_pipe<bf16_t>(a, pp, rne, st);
-  else
-    launch_pipe<f16_t>(a, pp, rne, st);
-  return check_launch("bvq_stats_fakequant_fwd/pipeline");
+  set_error("bvq_stats_fakequant_fwd: shape / layout not covered by the one-launch form");
+  return BVQ_ERR_UNSUPPORTED;
 }
 
 #endif  // forward part
@@ -1863,10 +1572,10 @@ extern "C" int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* d) {
   return bytes;
 }
 
-extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const void* x,
-                                 const void* scale, const void* zp, void* dx, float* dscale,
-                                 float* dzp, const void* tie_stat, int64_t* tie_info, void* workspace,
-                                 int64_t workspace_bytes, bvq_stream_t stream) {
+static int fakequant_bwd_impl(const bvq_quant_desc* d, const void* g, const void* x, const void* scale,
+                             const void* zp, void* dx, float* dscale, float* dzp, const void* tie_stat,
+                             int64_t* tie_info, void* workspace, int64_t workspace_bytes, bvq_stream_t stream,
+                             const LearnedScaleEpilogue* epilogue) {
   int rc = validate(d);
   if (rc) return rc;
   const int64_t n = d->outer * d->channels * d->inner;
@@ -1924,7 +1633,7 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
         float* folded = nullptr;
         launch_cols_fold_sum_min(ca.ds_part, nullptr, cp.prows, cp.L, ca.ds_part + cp.prows * cp.L, nullptr, &folded,
                                  nullptr, st);
-        launch_channel_sums(folded, nullptr, dscale, nullptr, 1, channels, d->inner, nullptr, st);
+        launch_channel_sums(folded, nullptr, dscale, nullptr, 1, channels, d->inner, nullptr, st, epilogue);
         rc = check_launch("bvq_fakequant_bwd/cols_sum");
       }
       return rc;
@@ -1936,6 +1645,9 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3, true), full);
   QuantArgs a = {};
   a.t = make_tiling(outer, channels, row_len, vec, 0, true);
+#ifdef BVQ_CACHE_EXPERIMENT
+  if (getenv("BVQ_X_BWD_REV")) a.t.reverse = atoi(getenv("BVQ_X_BWD_REV"));
+#endif
   int64_t mid_off = 0;
   if (need_sums) {
     // float partials (8-byte aligned end), then the doubles of a split reduction
@@ -1967,10 +1679,44 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
   if (rc) return rc;
   if (need_sums) {
     launch_channel_sums(dscale ? a.ds_part : nullptr, dzp ? a.dzp_part : nullptr, dscale, dzp, a.t.nob, channels,
-                        a.t.ppr, reinterpret_cast<char*>(workspace) + mid_off, st);
+                        a.t.ppr, reinterpret_cast<char*>(workspace) + mid_off, st, epilogue);
     rc = check_launch("bvq_fakequant_bwd/channel_sum");
   }
   return rc;
+}
+
+extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const void* x,
+                                 const void* scale, const void* zp, void* dx, float* dscale,
+                                 float* dzp, const void* tie_stat, int64_t* tie_info, void* workspace,
+                                 int64_t workspace_bytes, bvq_stream_t stream) {
+  return fakequant_bwd_impl(d, g, x, scale, zp, dx, dscale, dzp, tie_stat, tie_info, workspace, workspace_bytes,
+                            stream, nullptr);
+}
+
+extern "C" int bvq_fakequant_bwd_learned(const bvq_quant_desc* d, const void* g, const void* x, const void* scale,
+                                         const void* zp, void* dx, float* dscale, const void* value, int value_dtype,
+                                         double min_val, int use_min, double int_threshold, const void* gscale,
+                                         void* dvalue, void* workspace, int64_t workspace_bytes,
+                                         bvq_stream_t stream) {
+  if (!value || !dvalue || !dscale || value_dtype < BVQ_F32 || value_dtype > BVQ_F16) {
+    set_error("bvq_fakequant_bwd_learned: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  if (d && d->zp_per_channel) {
+    set_error("bvq_fakequant_bwd_learned: per-channel zero-points are not covered");
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  LearnedScaleEpilogue ep = {};
+  ep.value = value;
+  ep.dvalue = dvalue;
+  ep.gscale = gscale;
+  ep.value_dtype = value_dtype;
+  ep.scale_dtype = d ? d->scale_dtype : BVQ_F32;
+  ep.use_min = use_min;
+  ep.min_val = round_host((float)min_val, value_dtype);    // python scalar -> the parameter's dtype
+  ep.int_threshold = (float)int_threshold;                  // the caller rounds it to the division's dtype
+  return fakequant_bwd_impl(d, g, x, scale, zp, dx, dscale, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                            stream, &ep);
 }
 
 static bool bwd_stats_supported(const bvq_quant_desc* d, int64_t& units, int64_t& per_channel) {
@@ -2077,6 +1823,9 @@ extern "C" int bvq_fakequant_bwd_stats(const bvq_quant_desc* d, const void* g, c
   const int vec = snap_vec(pick_vec(full, d->outer * channels, d->inner, ptrs, els, 3, true), full);
   QuantArgs a = {};
   a.t = make_tiling(d->outer, channels, d->inner, vec, 0, true);
+#ifdef BVQ_CACHE_EXPERIMENT
+  if (getenv("BVQ_X_BWD_REV")) a.t.reverse = atoi(getenv("BVQ_X_BWD_REV"));
+#endif
   const int64_t pos_off = ((a.t.units * (int64_t)sizeof(float) + 7) / 8) * 8;
   if (workspace_bytes < pos_off + a.t.units * (int64_t)sizeof(unsigned long long)) {
     set_error("bvq_fakequant_bwd_stats: workspace too small");

@@ -836,7 +836,10 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
     return BVQ_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
-  const bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
+  bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
+#ifdef BVQ_CACHE_EXPERIMENT
+  if (getenv("BVQ_X_STAT_NT")) nt = atoi(getenv("BVQ_X_STAT_NT")) != 0;
+#endif
   // channel axis last (or nearly): column-mapped units, same finishing kernel
   const ColsPlan cp =
       (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? cols_plan(dtype, outer, channels, inner) : ColsPlan{};
@@ -891,6 +894,9 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
   int vec;
   StatArgs a;
   a.t = stat_tiling(dtype, x, nullptr, outer, channels, inner, vec, true);
+#ifdef BVQ_CACHE_EXPERIMENT
+  if (getenv("BVQ_X_STAT_REV")) a.t.reverse = atoi(getenv("BVQ_X_STAT_REV"));
+#endif
   const int32_t splits = finish_splits(a.t.nob * a.t.ppr);
   const int64_t mid_words = splits > 1 ? channels * (int64_t)splits : 0;
   const int64_t need = 2 * (a.t.units + mid_words) * (int64_t)sizeof(uint32_t);
@@ -1109,6 +1115,36 @@ extern "C" int bvq_scale_from_stat(const float* stat32, int64_t channels, int st
   scale_from_stat_kernel<<<dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
       stat32, stat_out, stat_dtype, ep, (int32_t)channels);
   return check_launch("bvq_scale_from_stat");
+}
+
+// learned scale, forward:  scale = |clamp_min_ste(value, min_val)| / int_threshold  in ONE launch
+// (ParameterScaling.forward, B/core/scaling/standalone.py:143-146, then the division of
+// RescalingIntQuant.forward, B/core/quant/int.py:160): clamp and |.| are exact, the quotient is rounded to
+// scale_dtype.  Its backward rides on the quantizer backward's last launch (bvq_fakequant_bwd_learned).
+__global__ void learned_scale_kernel(const void* __restrict__ value, int value_dtype, ScaleEpilogue ep, int32_t n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float v = load_scalar_as_f(value, value_dtype, c);
+  if (ep.use_min && v < ep.min_val) v = ep.min_val;  // NaN passes, like torch.clamp_min
+  store_stat(ep.scale_out, ep.scale_dtype, c, fabsf(v) / ep.int_threshold);
+}
+
+extern "C" int bvq_learned_scale(int value_dtype, const void* value, int64_t n, double min_val, int use_min,
+                                 double int_threshold, int scale_dtype, void* scale_out, bvq_stream_t stream) {
+  if (n < 1 || n > (1ll << 30) || bad_dtype(value_dtype) || bad_dtype(scale_dtype) || !value || !scale_out ||
+      !(int_threshold == int_threshold)) {
+    set_error("bvq_learned_scale: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  ScaleEpilogue ep;
+  ep.scale_out = scale_out;
+  ep.scale_dtype = scale_dtype;
+  ep.use_min = use_min;
+  ep.min_val = round_host((float)min_val, value_dtype);
+  ep.int_threshold = (float)int_threshold;
+  learned_scale_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(value, value_dtype, ep,
+                                                                                                 (int32_t)n);
+  return check_launch("bvq_learned_scale");
 }
 
 extern "C" int bvq_running_stats_update(int run_dtype, void* running, int stat_dtype, const void* stat,

@@ -19,6 +19,43 @@ static inline int32_t sum_splits(int64_t partials_per_channel) {
   return (int32_t)(s < 1 ? 1 : s);
 }
 
+// Optional epilogue of the LAST stage: the scale gradient out0[c] carried on, in the same launch, through the
+// backward of a learned scale   scale = abs_binary_sign_grad(clamp_min_ste(value, min_val)) / int_threshold
+// (ParameterScaling / ParameterFromRuntimeStatsScaling after collection, B/core/scaling/standalone.py:75-152,
+// 155-298; division B/core/quant/int.py:160) with torch's rounding points:
+//   ds  = dscale.to(scale_dtype) [+ gscale]                  gradient of `scale` (gscale: other users of scale)
+//   dt  = (ds / int_threshold  in scale_dtype).to(value dtype)   backward of the division
+//   dv  = binary_sign(clamp_min(value)) * dt                     backward of |.| ; clamp_min_ste passes it on
+// -- instead of a cast, a division, a sign-multiply and their launches.
+struct LearnedScaleEpilogue {
+  const void* value;   // [channels] the learned parameter; null: no epilogue
+  void* dvalue;        // [channels] its gradient, dtype of value
+  const void* gscale;  // nullable [channels], scale_dtype
+  float min_val;       // already rounded to the value's dtype
+  float int_threshold; // already rounded to the dtype the division runs in
+  int32_t value_dtype, scale_dtype, use_min;
+};
+
+__device__ __forceinline__ float round_to_dtype(float v, int dt) {
+  return dt == BVQ_F32 ? v : (dt == BVQ_BF16 ? rnd<bf16_t>(v) : rnd<f16_t>(v));
+}
+
+__device__ __forceinline__ void learned_scale_bwd_elem(const LearnedScaleEpilogue& ep, int32_t c, float dscale) {
+  float ds = round_to_dtype(dscale, ep.scale_dtype);
+  if (ep.gscale) ds = round_to_dtype(ds + load_scalar_as_f(ep.gscale, ep.scale_dtype, c), ep.scale_dtype);
+  const float dt = round_to_dtype(round_to_dtype(ds / ep.int_threshold, ep.scale_dtype), ep.value_dtype);
+  float v = load_scalar_as_f(ep.value, ep.value_dtype, c);
+  if (ep.use_min && v < ep.min_val) v = ep.min_val;  // NaN passes, like torch.clamp_min
+  const float sign = (float)(v >= 0.f) - (float)(v < 0.f);  // binary_sign: +1 at 0, 0 for NaN (B/function/ops.py:31-34)
+  const float dv = round_to_dtype(sign * dt, ep.value_dtype);
+  if (ep.value_dtype == BVQ_F32)
+    reinterpret_cast<float*>(ep.dvalue)[c] = dv;
+  else if (ep.value_dtype == BVQ_BF16)
+    reinterpret_cast<bf16_t*>(ep.dvalue)[c] = (bf16_t)dv;
+  else
+    reinterpret_cast<f16_t*>(ep.dvalue)[c] = (f16_t)dv;
+}
+
 template <typename PT>
 __global__ __launch_bounds__(kBlock) void channel_sum_kernel(const PT* __restrict__ part0,
                                                              const PT* __restrict__ part1,
@@ -26,7 +63,8 @@ __global__ __launch_bounds__(kBlock) void channel_sum_kernel(const PT* __restric
                                                              float* __restrict__ out1, int64_t nob,
                                                              int32_t channels, int64_t ppr,
                                                              double* __restrict__ mid0,
-                                                             double* __restrict__ mid1) {
+                                                             double* __restrict__ mid1,
+                                                             LearnedScaleEpilogue ep) {
   __shared__ double sh[2][kBlock];
   const int32_t c = blockIdx.x;
   const int64_t n = nob * ppr;
@@ -63,6 +101,7 @@ __global__ __launch_bounds__(kBlock) void channel_sum_kernel(const PT* __restric
     } else {
       if (out0) out0[c] = (float)sh[0][0];
       if (out1) out1[c] = (float)sh[1][0];
+      if (ep.value) learned_scale_bwd_elem(ep, c, (float)sh[0][0]);
     }
   }
 }
@@ -78,18 +117,20 @@ static inline int64_t channel_sums_mid_bytes(int64_t partials_per_channel, int64
 // mid: 8-byte aligned scratch of channel_sums_mid_bytes() bytes (unused if that is 0).
 static inline void launch_channel_sums(const float* part0, const float* part1, float* out0, float* out1,
                                        int64_t nob, int32_t channels, int64_t ppr, void* mid,
-                                       hipStream_t st) {
+                                       hipStream_t st, const LearnedScaleEpilogue* epilogue = nullptr) {
   const int32_t splits = sum_splits(nob * ppr);
+  const LearnedScaleEpilogue none = {};
+  const LearnedScaleEpilogue ep = epilogue ? *epilogue : none;
   if (splits > 1) {
     double* mid0 = reinterpret_cast<double*>(mid);
     double* mid1 = mid0 + (int64_t)channels * splits;
     channel_sum_kernel<float><<<dim3((unsigned)channels, (unsigned)splits), dim3(kBlock), 0, st>>>(
-        part0, part1, nullptr, nullptr, nob, channels, ppr, mid0, mid1);
+        part0, part1, nullptr, nullptr, nob, channels, ppr, mid0, mid1, none);
     channel_sum_kernel<double><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(
-        part0 ? mid0 : nullptr, part1 ? mid1 : nullptr, out0, out1, 1, channels, splits, nullptr, nullptr);
+        part0 ? mid0 : nullptr, part1 ? mid1 : nullptr, out0, out1, 1, channels, splits, nullptr, nullptr, ep);
   } else {
     channel_sum_kernel<float><<<dim3((unsigned)channels), dim3(kBlock), 0, st>>>(
-        part0, part1, out0, out1, nob, channels, ppr, nullptr, nullptr);
+        part0, part1, out0, out1, nob, channels, ppr, nullptr, nullptr, ep);
   }
 }
 

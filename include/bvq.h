@@ -355,18 +355,13 @@ int bvq_fakequant_fwd(const bvq_quant_desc* desc, const void* x, const void* sca
 /* Statistic AND quantizer in ONE launch: AbsMax over (outer, inner) -> clamp_min(min_val) -> / int_threshold
  * -> quantize-dequantize with that scale and a zero zero-point -- bvq_absmax_scale followed by
  * bvq_fakequant_fwd, i.e. RescalingIntQuant.forward on the stats-scaled graphs (B/core/quant/int.py:155-163,
- * B/core/scaling/runtime.py:50-72), in ONE launch, two forms:
- *   - a channel that fits the registers of one workgroup (weights, small activations) is read ONCE: held in
- *     registers between the reduction and the quantization (2 tensor passes instead of 3);
- *   - a per-channel tensor too large for the 256 MiB Infinity Cache is walked as a slab pipeline: the statistic
- *     of a slab of channels streams in from HBM while an earlier slab, still cache-resident, is quantized, so
- *     HBM sees one read of x and one write of y.  Workgroups hand the statistic over through agent-scope
- *     atomics; a quantizing wave whose slab's statistic has not arrived within a bounded number of polls
- *     computes it from x itself, so the launch finishes under any dispatch order or residency.
- * Uses desc's shape, dtypes (x_dtype == ct_dtype), qmin/qmax, round_mode, scalar_mode, pre_op, scale_dtype /
- * scale_per_channel; zero-point is +0.  stat_out: [channels] in x's dtype, scale_out: [channels] in scale_dtype.
- * bvq_stats_fakequant_fwd_workspace_bytes returns 0 when the shape is covered by neither form (ragged rows,
- * misaligned pointers, mid-sized channels): the caller then takes the two-call route. */
+ * B/core/scaling/runtime.py:50-72), in ONE launch, reading x ONCE: a channel that fits the registers of one
+ * workgroup (weights, small activations) is held there between the reduction and the quantization (2 tensor
+ * passes instead of 3, one launch instead of three).  Uses desc's shape, dtypes (x_dtype == ct_dtype), qmin/qmax,
+ * round_mode, scalar_mode, pre_op, scale_dtype / scale_per_channel; zero-point is +0.  stat_out: [channels] in
+ * x's dtype, scale_out: [channels] in scale_dtype.  bvq_stats_fakequant_fwd_workspace_bytes returns 0 when the
+ * shape is not covered (a channel larger than one workgroup's registers, ragged rows, misaligned pointers):
+ * the caller then takes the two-call route. */
 int64_t bvq_stats_fakequant_fwd_workspace_bytes(const bvq_quant_desc* desc, const void* x, const void* y);
 int bvq_stats_fakequant_fwd(const bvq_quant_desc* desc, const void* x, double min_val, int use_min,
                             double int_threshold, void* stat_out, void* scale_out, void* y, void* workspace,
@@ -390,6 +385,25 @@ int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* desc);
 int bvq_fakequant_bwd(const bvq_quant_desc* desc, const void* g, const void* x, const void* scale,
                       const void* zp, void* dx, float* dscale, float* dzp, const void* tie_stat,
                       int64_t* tie_info, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
+
+/* Learned scales (ParameterScaling, and ParameterFromRuntimeStatsScaling once its collection phase is over:
+ * the steady state of the default Int8ActPerTensorFloat; B/core/scaling/standalone.py:75-152, 155-298), float
+ * restriction:   scale = abs_binary_sign_grad(clamp_min_ste(value, min_val)) / int_threshold.
+ * bvq_learned_scale: that forward in ONE launch over the n (1 or `channels`) elements of `value`, the quotient
+ *   rounded to scale_dtype -- instead of clamp, |.|, division (3 launches).  min_val: python scalar (rounded to
+ *   value_dtype here); int_threshold: already rounded to the dtype the division runs in.
+ * bvq_fakequant_bwd_learned: bvq_fakequant_bwd(dscale) whose LAST reduction launch also carries the scale
+ *   gradient through that chain's backward with torch's rounding points --
+ *     dvalue = binary_sign(clamp_min(value)) * ((dscale.to(scale_dtype) [+ gscale]) / int_threshold)
+ *   (gscale, nullable, scale_dtype: gradient reaching `scale` from its other users) -- instead of a cast, a
+ *   division, a sign-multiply and their launches.  dscale (float32, 1 or `channels`) is still written.
+ *   Workspace: bvq_fakequant_bwd_workspace_bytes. */
+int bvq_learned_scale(int value_dtype, const void* value, int64_t n, double min_val, int use_min,
+                      double int_threshold, int scale_dtype, void* scale_out, bvq_stream_t stream);
+int bvq_fakequant_bwd_learned(const bvq_quant_desc* desc, const void* g, const void* x, const void* scale,
+                              const void* zp, void* dx, float* dscale, const void* value, int value_dtype,
+                              double min_val, int use_min, double int_threshold, const void* gscale,
+                              void* dvalue, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
 
 /* Backward of the stats-scaled per-channel graphs (scale = clamp_min(AbsMax(x)) / int_threshold) in
  * TWO launches: the backward kernel (dx, per-unit dscale sums, per-unit first position attaining `stat`) and one

@@ -1,0 +1,228 @@
+"""N > 1 path of the FUSED autograd function on CPU: world_size-2 gloo run of StatsFakeQuantFn with a `group`
+(brevitas_amd/core/quant/_fused.py: the sharded branches of forward -- local statistic, all-reduce(MAX), scale from
+the global statistic -- and of backward -- local scale-gradient sums merged with the gradient arriving through the
+`scale` output, one all-gather, tie ownership, deposit on the owning shard).
+
+The control flow under test is the product's; the kernels it would launch on a GPU are replaced here by
+oracle-backed test doubles behind `brevitas_amd._native.*` (the way tests/test_host_logic.py injects doubles; on the
+GPU box the real kernels are covered by the -m gpu tests).  Property checked, per-channel and per-tensor, float32:
+  batch-sharded == one process on the concatenated batch --
+  y of each shard bit-identical to the matching slice, scale and statistic identical on both ranks,
+  dx bit-identical away from the deposit, the deposit (value within the rounding of a reduced sum) on exactly the
+  shard and position the single-process run puts it (first arg-max in batch order / evenly over all ties).
+"""
+import os
+import socket
+from unittest import mock
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Doubles:
+    """oracle-backed stand-ins for the `_native` wrappers StatsFakeQuantFn calls on its sharded route"""
+
+    def __init__(self, O, nat):
+        self.O, self.nat = O, nat
+
+    def stats(self, kind, x, outer, channels, inner, out_f32=False, pre_op=0):
+        xn, dt = self.O.from_torch(x.reshape(-1))
+        out = self.O.stats(kind, xn, dt, outer, channels, inner, pre_op)
+        t = torch.from_numpy(np.asarray(out, dtype=np.float32).copy())
+        return t if out_f32 else t.to(x.dtype)
+
+    def scale_from_stat(self, stat32, stat_dtype, min_val, int_threshold, scale_dtype):
+        stat = stat32.to(stat_dtype)
+        thr = stat.clone()
+        if min_val:
+            mv = torch.tensor(min_val, dtype=stat_dtype)
+            thr = torch.where(thr < mv, mv, thr)
+        scale = (thr.float() / np.float32(int_threshold)).to(scale_dtype)
+        return stat, scale
+
+    def _desc(self, desc):
+        O = self.O
+        return O.make_desc(desc.outer, desc.channels, desc.inner, desc.x_dtype, desc.ct_dtype, desc.scale_dtype,
+                           desc.zp_dtype, scale_per_channel=bool(desc.scale_per_channel),
+                           zp_per_channel=bool(desc.zp_per_channel), qmin=desc.qmin, qmax=desc.qmax,
+                           round_mode=desc.round_mode, scalar_mode=desc.scalar_mode, clamp_ste=bool(desc.clamp_ste),
+                           out_kind=desc.out_kind, pre_op=desc.pre_op)
+
+    def fakequant_fwd(self, desc, x, scale, zp, want_codes=False, want_y=True):
+        O = self.O
+        xn, dt = O.from_torch(x.reshape(-1))
+        sn, _ = O.from_torch(scale.reshape(-1))
+        zn, _ = O.from_torch(zp.reshape(-1))
+        y, _ = O.fakequant_fwd(self._desc(desc), xn, sn, zn, want_codes=False)
+        return O.to_torch(y, desc.ct_dtype).reshape(x.shape)
+
+    def fakequant_bwd(self, desc, g, x, scale, zp, need_dscale, need_dzp, tie_stat=None):
+        O = self.O
+        xn, _ = O.from_torch(x.reshape(-1))
+        gn, _ = O.from_torch(g.reshape(-1))
+        sn, _ = O.from_torch(scale.reshape(-1))
+        zn, _ = O.from_torch(zp.reshape(-1))
+        dx, ds, dz = O.fakequant_bwd(self._desc(desc), gn, xn, sn, zn)
+        dx = O.to_torch(dx, desc.x_dtype).reshape(x.shape)
+        ds = torch.from_numpy(ds.copy())
+        pc = bool(desc.scale_per_channel) and desc.channels > 1
+        ch = int(desc.channels) if pc else 1
+        # what the backward kernel records about the elements attaining the statistic (include/bvq.h, tie_info)
+        info = torch.full((max(ch, 2 + 1024),), -1, dtype=torch.int64)
+        ax = x.detach().abs().float().reshape(desc.outer, desc.channels, desc.inner) if pc else \
+            x.detach().abs().float().reshape(1, 1, -1)
+        st = tie_stat.detach().float().reshape(-1)
+        if pc:
+            for c in range(ch):
+                hit = torch.nonzero(ax[:, c, :].reshape(-1) == st[c]).reshape(-1)
+                info[c] = int(hit[0]) if hit.numel() else -1
+        else:
+            hit = torch.nonzero(ax.reshape(-1) == st[0]).reshape(-1)
+            info[0] = hit.numel()
+            info[1] = 0
+            info[2:2 + hit.numel()] = hit
+        return dx, ds, None, info
+
+    def stat_tie_apply(self, match, x, stat, gstat, info, dx, outer, channels, inner, mode_add, total_ties=None,
+                       pre_op=0):
+        assert mode_add
+        xf = x.detach().reshape(-1)
+        gs = gstat.to(x.dtype).reshape(-1)
+        flat = dx.reshape(-1)
+        if channels > 1:
+            for c in range(channels):
+                pos = int(info[c])
+                if pos < 0:
+                    continue
+                o, i = divmod(pos, inner)
+                idx = (o * channels + c) * inner + i
+                flat[idx] += torch.sign(xf[idx]) * gs[c]
+        else:
+            n_local = int(info[0])
+            total = int(total_ties[0]) if total_ties is not None else n_local
+            for idx in info[2:2 + n_local].tolist():
+                flat[idx] += torch.sign(xf[idx]) * (gs[0] / total)
+        return dx
+
+
+def _expected_full(O, x, g, h, ch, inner, per_channel, world):
+    """single process on the concatenated batch, from the oracle: y, dx with the deposit, scale"""
+    n = x.shape[0]
+    lay = (n, ch, inner) if per_channel else (1, 1, x.numel())
+    xn = x.reshape(-1).numpy().copy()
+    gn = g.reshape(-1).numpy().copy()
+    stat = O.stats(O.STAT_ABSMAX, xn, O.F32, *lay)
+    scale = (np.maximum(stat, np.float32(1e-10)) / np.float32(128.0)).astype(np.float32)
+    zp = np.zeros(1, dtype=np.float32)
+    d = O.make_desc(*lay, O.F32, O.F32, O.F32, scale_per_channel=per_channel, qmin=-128.0, qmax=127.0)
+    y, _ = O.fakequant_fwd(d, xn, scale, zp, want_codes=False)
+    dx, ds, _ = O.fakequant_bwd(d, gn, xn, scale, zp)
+    ds = ds.astype(np.float64) + world * h.numpy().reshape(-1).astype(np.float64)  # every rank's loss uses `scale`
+    dstat = (ds / 128.0).astype(np.float32)
+    dx = dx.copy()
+    deposit = {}
+    if per_channel:
+        ax = np.abs(x.numpy().reshape(n, ch, inner))
+        for c in range(ch):
+            hit = np.nonzero(ax[:, c, :].reshape(-1) == stat[c])[0]
+            o, i = divmod(int(hit[0]), inner)
+            idx = (o * ch + c) * inner + i
+            deposit[idx] = np.sign(xn[idx]) * dstat[c]
+    else:
+        hits = np.nonzero(np.abs(xn) == stat[0])[0]
+        for idx in hits:
+            deposit[int(idx)] = np.sign(xn[idx]) * dstat[0] / len(hits)
+    return y, dx, scale, stat, deposit
+
+
+def _worker(rank, world, port, per_channel, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import oracle as O
+    from brevitas_amd import _native as nat
+    from brevitas_amd.core.quant import _fused
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        gen = torch.Generator().manual_seed(123456)
+        n, c, hh, ww = 4, 6, 5, 4
+        inner = hh * ww
+        x = torch.randn(n, c, hh, ww, generator=gen)
+        x[3, 2, 1, 1] = 9.0   # channel 2's maximum lives in the second shard
+        x[0, 4, 0, 0] = -7.5
+        x[2, 4, 2, 2] = 7.5   # a +-max tie across shards: the first (rank 0) must own channel 4's deposit
+        if not per_channel:
+            x[0, 0, 0, 0] = -9.0  # whole-tensor maximum tied between the two shards (with x[3,2,1,1])
+        g = torch.randn(n, c, hh, ww, generator=gen)
+        ch = c if per_channel else 1
+        h = torch.randn(ch, generator=gen)  # gradient arriving through the `scale` output, the same on every rank
+        per = n // world
+        xs = x[rank * per:(rank + 1) * per].clone().requires_grad_(True)
+        gs = g[rank * per:(rank + 1) * per]
+        sp = _fused.StatsPlan(per if per_channel else 1, ch, inner if per_channel else xs.numel(),
+                              (1, c, 1, 1) if per_channel else (), 1e-10, 128.0)
+        dbl = Doubles(O, nat)
+        with mock.patch.object(nat, 'stats', dbl.stats), mock.patch.object(nat, 'scale_from_stat', dbl.scale_from_stat), \
+                mock.patch.object(nat, 'fakequant_fwd', dbl.fakequant_fwd), \
+                mock.patch.object(nat, 'fakequant_bwd', dbl.fakequant_bwd), \
+                mock.patch.object(nat, 'stat_tie_apply', dbl.stat_tie_apply):
+            y, scale, stat = _fused.StatsFakeQuantFn.apply(xs, torch.tensor(128.0), sp, -128.0, 127.0, nat.ROUND, False,
+                                                           dist.group.WORLD, nat.PRE_NONE)
+            loss = (y * gs).sum() + (scale.reshape(-1) * h).sum()
+            loss.backward()
+        y_full, dx_full, scale_full, stat_full, deposit = _expected_full(O, x, g, h, c if per_channel else 1, inner,
+                                                                         per_channel, world)
+        # forward: global statistic and scale on every rank, y equal to the matching slice, bit for bit
+        assert np.array_equal(stat.detach().numpy().reshape(-1), stat_full)
+        assert np.array_equal(scale.detach().numpy().reshape(-1), scale_full)
+        lo, hi = rank * per * c * inner, (rank + 1) * per * c * inner
+        assert np.array_equal(y.detach().numpy().reshape(-1), y_full[lo:hi])
+        # backward: dx of this shard == the slice of the full-batch dx; deposits only where the full run puts them
+        got = xs.grad.numpy().reshape(-1)
+        want = dx_full[lo:hi].copy()
+        mine = {i - lo: v for i, v in deposit.items() if lo <= i < hi}
+        diff = np.nonzero(got != want)[0]
+        assert set(diff.tolist()) <= set(mine), (rank, diff.tolist(), sorted(mine))
+        for i, v in mine.items():
+            assert abs(got[i] - (want[i] + v)) <= 1e-5 * max(1.0, abs(v)), (rank, i, got[i], want[i] + v)
+        # and every deposit of the full run landed on exactly one shard
+        count = torch.tensor([len(mine)])
+        dist.all_reduce(count)
+        assert int(count) == len(deposit)
+        q.put((rank, 'ok'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('per_channel', [True, False], ids=['per_channel', 'per_tensor'])
+def test_sharded_fused_function_equals_full_batch(oracle, per_channel):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per_channel, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    results = [q.get(timeout=5) for _ in range(world)]
+    for rank, msg in results:
+        assert msg == 'ok', 'rank %d failed:\n%s' % (rank, msg)
+    assert all(p.exitcode == 0 for p in procs)

@@ -10,7 +10,7 @@ import torch
 
 import golden_util as G
 from test_gpu_modules import assert_bits, to_np
-from test_gpu_shifted import _dx_check
+from test_gpu_shifted import _dx_check  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -39,6 +39,9 @@ def _check_dvalue(got, c, x, g, scale, qmin, qmax):
     0-dim float32 scale next to a bf16 tensor), and the golden number only within bf16 summation error."""
     got = float(got)
     want = float(c.f32('dvalue'))
+    if DEV == 'cpu':  # the pure-torch route sums the same bf16 terms in the same order as the reference
+        assert abs(got - want) <= 2e-3 * abs(want) + 1e-6, (got, want)
+        return
     if c['dtype'] == 'f32':
         assert abs(got - want) <= 2e-3 * abs(want) + 1e-6, (got, want)
         return
@@ -69,7 +72,7 @@ def _is_pot(t):
 def test_pot_weight(c):
     import brevitas_amd.quant as Q
     w = torch.nn.Parameter(c.torch('x', DEV))
-    build = Q.Int8WeightPerChannelFixedPoint if c['tag'] == 'per_channel' else Q.Int8WeightPerTensorFixedPoint
+    build = Q.Int8WeightPerChannelFixedPoint if c['tag'].startswith('per_channel') else Q.Int8WeightPerTensorFixedPoint
     q = build(w).to(DEV)
     y, scale, zp, bw = q(w)
     # a channel whose statistic is zero takes the lower bound 1e-10 (MaxStatsScaling.scaling_min_val,

@@ -222,18 +222,10 @@ def test_weight_configs_vs_oracle(nat, oracle, shape, dtype, bit_width):
     assert diff.size <= cout  # only the per-channel arg-max deposits (oracle step has no deposit)
 
 
-def test_full_size_one_kernel_forward(nat, act):
-    """statistic + quantizer in one launch on the [256,512,56,56] activation (the slab pipeline through the
-    Infinity Cache, the product default at this size) == the two-kernel route, bit for bit; repeated to catch
-    a torn hand-off between workgroups"""
+def test_full_size_forward_takes_the_two_kernel_route(nat, act):
+    """the one-launch forward covers channels that fit one workgroup's registers; the [256,512,56,56] activation
+    (1.6 MB per channel) must report "not covered" so that the module takes statistic kernel + quantizer kernel"""
     x, _ = act
     N, C, H, W = x.shape
-    flat = x.reshape(-1)
     d = nat.QuantDesc(N, C, H * W, nat.BF16, nat.BF16, nat.BF16, nat.F32, 1, 0, -128.0, 127.0, 0, 0, 0, 0)
-    stat, scale = nat.absmax_scale(flat, N, C, H * W, 1e-10, 128.0, torch.bfloat16)
-    y = nat.fakequant_fwd(d, flat, scale, torch.zeros(1, device=DEV))
-    for _ in range(5):
-        fused = nat.stats_fakequant_fwd(d, flat, 1e-10, 128.0, torch.bfloat16)
-        assert fused is not None
-        assert torch.equal(fused[0], stat) and torch.equal(fused[1], scale)
-        assert torch.equal(bits(fused[2]), bits(y))
+    assert nat.stats_fakequant_fwd(d, x.reshape(-1), 1e-10, 128.0, torch.bfloat16) is None

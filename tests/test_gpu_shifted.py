@@ -22,10 +22,11 @@ def cpu_scalar_semantics(monkeypatch):
 
 def _dx_check(dx, c, max_deposits):
     got, want = to_np(dx).reshape(-1), c.arr('dx').reshape(-1)
-    bad = np.nonzero(got != want)[0]
-    assert bad.size <= max_deposits, (bad.size, max_deposits)
     gf = dx.detach().float().cpu().numpy().reshape(-1)
     wf = c.f32('dx').reshape(-1)
+    # (a NaN gradient -- log2 of an all-zero statistic, as in the reference -- equals a NaN gradient)
+    bad = np.nonzero((got != want) & ~(np.isnan(gf) & np.isnan(wf)))[0]
+    assert bad.size <= max_deposits, (bad.size, max_deposits)
     scale = max(1.0, float(np.abs(wf).max()))
     tol = {'f32': 2e-4, 'bf16': 2.0 ** -5}[c['dtypes']['dx']] * 64 * scale
     assert np.all(np.abs(gf[bad] - wf[bad]) <= tol), (gf[bad], wf[bad])

@@ -78,8 +78,15 @@ def test_tracing_emits_plain_ops():
     assert torch.equal(traced(x), torch.floor(torch.round(x) + 0.25))
 
 
-def test_cpu_tensor_fails_loudly():
-    """no CPU fallback: the product path refuses tensors that are not on a ROCm device"""
-    from brevitas_amd._native import BvqError
-    with pytest.raises(BvqError, match='no CPU fallback'):
-        ops_ste.round_ste(torch.randn(4))
+def test_cpu_tensors_take_the_pure_torch_route_and_the_hip_library_refuses_them():
+    """a CPU tensor runs the reference's own op composition on ATen (brevitas_amd._aten; SURVEY 8b "Errors"); the
+    HIP library itself never touches host memory: its wrappers refuse a CPU tensor loudly"""
+    from brevitas_amd import _aten, _native
+    x = torch.tensor([0.5, 1.5, -2.5, 2.4], requires_grad=True)
+    y = ops_ste.round_ste(x)
+    assert torch.equal(y.detach(), torch.tensor([0., 2., -2., 2.]))  # half to even, like torch.round
+    y.sum().backward()
+    assert torch.equal(x.grad, torch.ones(4))                         # straight-through
+    assert _aten.for_tensor(x) is _aten
+    with pytest.raises(_native.BvqError, match='only runs on a ROCm'):
+        _native.unary(_native.OP_ROUND, torch.randn(4))
