@@ -38,7 +38,7 @@ EXPORTS = (
     'bvq_abs_affine_bwd', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_pair', 'bvq_kth_passes',
     'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd',
     'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd_stats_workspace_bytes', 'bvq_fakequant_bwd_stats', 'bvq_fakequant_bwd',
-    'bvq_learned_scale', 'bvq_fakequant_bwd_learned')
+    'bvq_learned_scale', 'bvq_fakequant_bwd_learned', 'bvq_variant_fwd', 'bvq_variant_bwd_workspace_bytes', 'bvq_variant_bwd')
 
 
 class QuantDesc(ctypes.Structure):
@@ -52,11 +52,24 @@ class QuantDesc(ctypes.Structure):
         ('out_kind', ctypes.c_int32), ('pre_op', ctypes.c_int32), ('codes_dtype', ctypes.c_int32)]
 
 
+class VariantDesc(ctypes.Structure):
+    """bvq_variant_desc of include/bvq.h"""
+    _fields_ = [
+        ('outer', ctypes.c_int64), ('channels', ctypes.c_int64), ('inner', ctypes.c_int64), ('kind', ctypes.c_int32),
+        ('x_dtype', ctypes.c_int32), ('ct_dtype', ctypes.c_int32), ('scale_dtype', ctypes.c_int32),
+        ('zp_dtype', ctypes.c_int32), ('scale_per_channel', ctypes.c_int32), ('round_mode', ctypes.c_int32),
+        ('clamp_ste', ctypes.c_int32), ('scalar_mode', ctypes.c_int32), ('qmin', ctypes.c_float),
+        ('qmax', ctypes.c_float), ('threshold', ctypes.c_float), ('trunc_scale', ctypes.c_float)]
+
+
+VAR_BINARY, VAR_CLAMPED_BINARY, VAR_TERNARY, VAR_DECOUPLED, VAR_TRUNC = range(5)
+
+
 class BvqError(RuntimeError):
     pass
 
 
-def _load(path=None):
+def _load(path=None, strict=True):
     path = path or LIB_PATH
     if not os.path.exists(path):
         raise ImportError(
@@ -105,10 +118,17 @@ def _load(path=None):
         'bvq_stat_tie_apply_dscale': (i32, [i32, i32, vp, vp, vp, i32, dbl, i32, vp, vp, vp, i64, i64, i64, vp]),
         'bvq_fakequant_bwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
         'bvq_learned_scale': (i32, [i32, vp, i64, dbl, i32, dbl, i32, vp, vp]),
+        'bvq_variant_fwd': (i32, [ctypes.POINTER(VariantDesc), vp, vp, vp, vp, vp, vp, vp]),
+        'bvq_variant_bwd_workspace_bytes': (i64, [ctypes.POINTER(VariantDesc)]),
+        'bvq_variant_bwd': (i32, [ctypes.POINTER(VariantDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
         'bvq_fakequant_bwd_learned': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, i32, dbl, i32, dbl, vp, vp, vp, i64, vp]),
     }
     for name, (res, args) in sig.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:
+            if strict:
+                raise ImportError('brevitas_amd: %s does not export %s' % (path, name))
+            continue  # developer A/B runs against an older build (tools/variant_bench.py)
         fn.restype = res
         fn.argtypes = args
     ver = lib.bvq_abi_version()
@@ -594,6 +614,36 @@ def fakequant_bwd_stats(desc, g, x, scale, zp, stat, scale_dtype, int_threshold,
         if _timer is not None:
             _timer.after('bvq_fakequant_bwd')
     return (dx, ds) if want_dscale else dx
+
+
+def variant_fwd(desc, x, scale, pre_scale=None, zp=None, pre_zp=None):
+    """forward of the sign / decoupled / truncating quantizers (include/bvq.h, bvq_variant_fwd) -> y in desc.ct_dtype"""
+    dev = require_device(x, scale, pre_scale, zp, pre_zp)
+    ct = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[desc.ct_dtype]
+    y = torch.empty(x.shape, dtype=ct, device=dev)
+    with _DeviceGuard(dev):
+        check(lib.bvq_variant_fwd(ctypes.byref(desc), ptr(x), ptr(scale), ptr(pre_scale), ptr(zp), ptr(pre_zp), ptr(y),
+                                  stream_ptr(dev)), 'bvq_variant_fwd')
+    return y
+
+
+def variant_bwd(desc, g, x, scale, pre_scale=None, zp=None, pre_zp=None, need_dscale=False, need_dpre=False):
+    """-> (dx, dscale float32 or None, dpre_scale float32 or None)"""
+    dev = require_device(g, x, scale, pre_scale, zp, pre_zp)
+    dx = torch.empty_like(x)
+    nsum = int(desc.channels) if (desc.scale_per_channel and desc.channels > 1) else 1
+    ds = torch.empty(nsum, dtype=torch.float32, device=dev) if need_dscale else None
+    dp = torch.empty(nsum, dtype=torch.float32, device=dev) if need_dpre else None
+    ws, wsb = None, 0
+    if need_dscale or need_dpre:
+        wsb = int(lib.bvq_variant_bwd_workspace_bytes(ctypes.byref(desc)))
+        if wsb < 0:
+            raise BvqError('bvq_variant_bwd_workspace_bytes: ' + last_error())
+        ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
+    with _DeviceGuard(dev):
+        check(lib.bvq_variant_bwd(ctypes.byref(desc), ptr(g), ptr(x), ptr(scale), ptr(pre_scale), ptr(zp), ptr(pre_zp),
+                                  ptr(dx), ptr(ds), ptr(dp), ptr(ws), wsb, stream_ptr(dev)), 'bvq_variant_bwd')
+    return dx, ds, dp
 
 
 def learned_scale(value, min_val, int_threshold, scale_dtype):

@@ -215,6 +215,61 @@ class LearnedScaleFakeQuantFn(Function):
         return dx, dvalue.view(value.shape), None, None, None, None, None, None, None, None, None
 
 
+class VariantFn(Function):
+    """BinaryQuant / ClampedBinaryQuant / TernaryQuant / DecoupledIntQuant / TruncIntQuant on their fused kernels
+    (include/bvq.h, bvq_variant_fwd / bvq_variant_bwd): one read + one write forward, two reads + one write backward,
+    the scale gradients on the same reads.  `opts`: kind plus the kind's parameters (variant_plan below)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, pre_scale, zp, pre_zp, p, opts):
+        xc = x.contiguous()
+        sc = scale.reshape(-1).contiguous()
+        ps = pre_scale.reshape(-1).contiguous() if pre_scale is not None else None
+        zc = zp.reshape(-1).contiguous() if zp is not None else None
+        pz = pre_zp.reshape(-1).contiguous() if pre_zp is not None else None
+        zdt = (zc if zc is not None else pz if pz is not None else _zero_zero_point(x.device)).dtype
+        desc = nat.VariantDesc(p.outer, p.channels, p.inner, opts['kind'], nat.dtype_code(x.dtype),
+                               nat.dtype_code(opts['ct']), nat.dtype_code(sc.dtype), nat.dtype_code(zdt), int(p.scale_pc),
+                               opts.get('round_mode', nat.ROUND), int(opts.get('clamp_ste', False)), scalar_mode(),
+                               opts.get('qmin', 0.0), opts.get('qmax', 0.0), opts.get('threshold', 0.0),
+                               opts.get('trunc_scale', 1.0))
+        y = nat.variant_fwd(desc, xc, sc, ps, zc, pz)
+        ctx.desc = desc
+        ctx.save_for_backward(xc, sc, ps, zc, pz)
+        ctx.shapes = (scale.shape, scale.dtype, None if pre_scale is None else (pre_scale.shape, pre_scale.dtype))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, sc, ps, zc, pz = ctx.saved_tensors
+        desc = ctx.desc
+        ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
+        need_ds, need_dp = ctx.needs_input_grad[1], ctx.needs_input_grad[2] and ps is not None
+        dx, ds, dp = nat.variant_bwd(desc, gy.to(ct).contiguous(), xc, sc, ps, zc, pz, need_ds, need_dp)
+        sshape, sdt, pre = ctx.shapes
+        ds = ds.reshape(sshape).to(sdt) if need_ds else None
+        dp = dp.reshape(pre[0]).to(pre[1]) if need_dp else None
+        return (dx if ctx.needs_input_grad[0] else None), ds, dp, None, None, None, None
+
+
+def variant_plan(x: Tensor, scale: Tensor, *others: Optional[Tensor]) -> Optional[Plan]:
+    """layout plan for a variant kernel: x against `scale`; every other scale-like operand must share scale's shape
+    and dtype, every zero-point must be a single element that needs no gradient"""
+    if not config.FUSED_PATHS or torch._C._get_tracing_state() is not None:
+        return None
+    p = plan(x, scale, _zero_zero_point(x.device) if x.is_cuda else scale)
+    if p is None or p.nhwc or not x.is_contiguous():
+        return None
+    for t in others:
+        if t is not None and (t.shape != scale.shape or t.dtype != scale.dtype or not t.is_cuda):
+            return None
+    return p
+
+
+def scalar_zero_point_ok(*zps: Optional[Tensor]) -> bool:
+    return all(z is None or (z.numel() == 1 and z.is_cuda and z.dtype in _FLOATS and not z.requires_grad) for z in zps)
+
+
 class StatsPlan(NamedTuple):
     outer: int
     channels: int

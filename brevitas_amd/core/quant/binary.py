@@ -1,5 +1,7 @@
-"""Binary quantizers (drop-ins for B/core/quant/binary.py): sign(x) * scale through the HIP-backed
-straight-through ops; same constructors, outputs and state."""
+"""Binary quantizers (drop-ins for B/core/quant/binary.py): same constructors, outputs and state.  On a device
+tensor  [clamp ->] sign -> * scale  is ONE kernel, and its autograd (sign straight-through, clamp mask, the scale
+gradient incl. what the clamp bounds receive) one more (include/bvq.h, bvq_variant_fwd / bvq_variant_bwd); anything
+the kernels do not cover runs the reference's op sequence on the straight-through ops."""
 from typing import Tuple
 
 import torch
@@ -9,8 +11,22 @@ from torch.nn import Module
 from brevitas_amd.core.bit_width import BitWidthConst
 from brevitas_amd.core.function_wrapper import TensorClamp
 from brevitas_amd.core.quant.delay import DelayWrapper
+from brevitas_amd import _native as nat
+from brevitas_amd.core.quant import _fused
 from brevitas_amd.core.utils import StatelessBuffer
 from brevitas_amd.function.ops_ste import binary_sign_ste
+
+
+def _sign_kernel(x: Tensor, scale: Tensor, kind: int, clamp_ste: bool = False, threshold: float = 0.0, ct=None):
+    """y of a sign quantizer on its fused kernel, or None if the operands are not covered"""
+    p = _fused.variant_plan(x, scale)
+    if p is None:
+        return None
+    ct = ct if ct is not None else torch.result_type(x, scale)
+    if not (ct == x.dtype or ct == torch.float32):
+        return None
+    return _fused.VariantFn.apply(x, scale, None, None, None, p,
+                                  dict(kind=kind, ct=ct, clamp_ste=clamp_ste, threshold=threshold))
 
 
 class BinaryQuant(torch.nn.Module):
@@ -25,7 +41,9 @@ class BinaryQuant(torch.nn.Module):
 
     def forward(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
         scale = self.scaling_impl(x)
-        y = binary_sign_ste(x) * scale
+        y = _sign_kernel(x, scale, nat.VAR_BINARY)
+        if y is None:
+            y = binary_sign_ste(x) * scale
         y = self.delay_wrapper(x, y)
         return y, scale, self.zero_point(), self.bit_width()
 
@@ -44,7 +62,10 @@ class ClampedBinaryQuant(torch.nn.Module):
 
     def forward(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
         scale = self.scaling_impl(x)
-        y = self.tensor_clamp_impl(x, -scale, scale)
-        y = binary_sign_ste(y) * scale
+        clamp_ste = getattr(self.tensor_clamp_impl, 'bvq_clamp_ste', None)
+        y = _sign_kernel(x, scale, nat.VAR_CLAMPED_BINARY, clamp_ste) if clamp_ste is not None else None
+        if y is None:
+            y = self.tensor_clamp_impl(x, -scale, scale)
+            y = binary_sign_ste(y) * scale
         y = self.delay_wrapper(x, y)
         return y, scale, self.zero_point(), self.bit_width()

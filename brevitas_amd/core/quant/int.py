@@ -176,10 +176,11 @@ class RescalingIntQuant(torch.nn.Module):
         if p is None or p.zp_pc:
             return None
         int_thr = self.int_scaling_impl.host_value(bw)
-        if value.dim() > 0:  # a dimensioned threshold keeps its dtype: the 0-dim float32 int_threshold is converted
+        if value.dim() > 0:  # a dimensioned threshold keeps its dtype: the 0-dim int_threshold is converted to it
             scale_dtype, thr_div = value.dtype, _fused._as_dtype_value(int_thr, value.dtype)
-        else:
-            scale_dtype, thr_div = torch.promote_types(value.dtype, torch.float32), int_thr
+        else:                # two 0-dim operands promote like tensors (int_threshold has the bit width's dtype)
+            scale_dtype = torch.promote_types(value.dtype, bit_width.dtype)
+            thr_div = _fused._as_dtype_value(int_thr, bit_width.dtype)
         qmin, qmax = int_range_host(iq.signed, iq.narrow_range, bw)
         return value, min_val, p, thr_div, scale_dtype, qmin, qmax, round_mode, clamp_ste
 
@@ -352,10 +353,24 @@ class TruncIntQuant(torch.nn.Module):
     def forward(self, x: Tensor, scale: Tensor, zero_point: Tensor, input_bit_width: Tensor
                 ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
         from brevitas_amd.function.ops_ste import round_ste
+        output_bit_width = self.msb_clamp_bit_width_impl()
+        # both bit widths known on the host (constant bit widths handed on by the layers): the whole chain is ONE
+        # kernel, its autograd one more (include/bvq.h, bvq_variant_fwd: BVQ_VAR_TRUNC)
+        in_bw = getattr(input_bit_width, 'bvq_host_value', None)
+        out_bw = getattr(output_bit_width, 'bvq_host_value', None)
+        round_mode = getattr(self.float_to_int_impl, 'bvq_round_mode', None)
+        if in_bw is not None and out_bw is not None and round_mode is not None and \
+                _fused.scalar_zero_point_ok(zero_point):
+            p = _fused.variant_plan(x, scale)
+            ct = torch.result_type(x, scale)
+            if p is not None and (ct == x.dtype or ct == torch.float32):
+                y = _fused.VariantFn.apply(x, scale, None, zero_point, None, p,
+                                           dict(kind=nat.VAR_TRUNC, ct=ct, round_mode=round_mode,
+                                                trunc_scale=float(2.0 ** (in_bw - out_bw))))
+                return self.delay_wrapper(x, y), scale, zero_point, output_bit_width
         y = x / scale
         y = y + zero_point
         y = round_ste(y)  # clean up floating point error
-        output_bit_width = self.msb_clamp_bit_width_impl()
         trunc_bit_width = input_bit_width - output_bit_width
         trunc_scale = 2.0 ** trunc_bit_width
         y = y / trunc_scale

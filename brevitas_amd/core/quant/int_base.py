@@ -169,8 +169,31 @@ class DecoupledIntQuant(torch.nn.Module):
     def max_int(self, bit_width):
         return max_int(self.signed, self.narrow_range, bit_width)
 
+    def _fused_forward(self, pre_scale, pre_zero_point, scale, zero_point, bit_width, x):
+        """the whole chain as one kernel (and its autograd as one more), or None if not covered"""
+        round_mode = getattr(self.float_to_int_impl, 'bvq_round_mode', None)
+        clamp_ste = getattr(self.tensor_clamp_impl, 'bvq_clamp_ste', None)
+        bw = getattr(bit_width, 'bvq_host_value', None)
+        if round_mode is None or clamp_ste is None or bw is None or bit_width.requires_grad:
+            return None
+        if not _fused.scalar_zero_point_ok(zero_point, pre_zero_point):
+            return None
+        p = _fused.variant_plan(x, scale, pre_scale)
+        if p is None:
+            return None
+        ct = torch.result_type(x, pre_scale)
+        if not (ct == x.dtype or ct == torch.float32) or zero_point.dtype != pre_zero_point.dtype:
+            return None
+        qmin, qmax = int_range_host(self.signed, self.narrow_range, bw)
+        return _fused.VariantFn.apply(x, scale, pre_scale, zero_point, pre_zero_point, p,
+                                      dict(kind=nat.VAR_DECOUPLED, ct=ct, round_mode=round_mode, clamp_ste=clamp_ste,
+                                           qmin=qmin, qmax=qmax))
+
     def forward(self, pre_scale: Tensor, pre_zero_point: Tensor, scale: Tensor, zero_point: Tensor, bit_width: Tensor,
                 x: Tensor) -> Tensor:
+        y = self._fused_forward(pre_scale, pre_zero_point, scale, zero_point, bit_width, x)
+        if y is not None:
+            return self.delay_wrapper(x, y)
         y_int = self.to_int(pre_scale, pre_zero_point, bit_width, x)
         y = y_int - zero_point
         y = y * scale

@@ -1,4 +1,5 @@
-"""Ternary quantizer (drop-in for B/core/quant/ternary.py:15-66)."""
+"""Ternary quantizer (drop-in for B/core/quant/ternary.py:15-66): on a device tensor the dead-zone mask, the sign
+and the scaling are ONE kernel, their autograd one more (include/bvq.h, bvq_variant_fwd / bvq_variant_bwd)."""
 from typing import Tuple
 
 import torch
@@ -30,6 +31,13 @@ class TernaryQuant(torch.nn.Module):
 
     def forward(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
         scale = self.scaling_impl(x)
+        from brevitas_amd import _native as nat
+        from brevitas_amd.core.quant.binary import _sign_kernel
+        # mask.float() * sign(x) * scale computes in float32 whatever x's dtype is (B/core/quant/ternary.py:64-66)
+        fused = _sign_kernel(x, scale, nat.VAR_TERNARY, threshold=float(self.threshold), ct=torch.float32) \
+            if scale.dtype != torch.float64 else None
+        if fused is not None:
+            return self.delay_wrapper(x, fused), scale, self.zero_point(), self.bit_width()
         # {-1, 0, +1}: zero inside the dead zone |x| <= threshold * scale, the sign outside (gradient passes through)
         outside = torch.abs(x) > self.threshold * scale
         y = self.delay_wrapper(x, outside.float() * ternary_sign_ste(x) * scale)

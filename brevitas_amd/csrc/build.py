@@ -20,7 +20,7 @@ OBJ_DIR = os.path.join(ROOT, 'build', 'bvq')
 
 # (source, extra -D flags, object name): the quantizer file is split into its forward and backward halves
 SOURCES = [('bvq_common.hip', [], 'bvq_common.o'), ('bvq_elementwise.hip', [], 'bvq_elementwise.o'),
-           ('bvq_stats.hip', [], 'bvq_stats.o'), ('bvq_select.hip', [], 'bvq_select.o'), ('bvq_fakequant.hip', ['BVQ_PART=1'], 'bvq_fakequant_fwd.o'),
+           ('bvq_stats.hip', [], 'bvq_stats.o'), ('bvq_select.hip', [], 'bvq_select.o'), ('bvq_variants.hip', [], 'bvq_variants.o'), ('bvq_fakequant.hip', ['BVQ_PART=1'], 'bvq_fakequant_fwd.o'),
            ('bvq_fakequant.hip', ['BVQ_PART=2'], 'bvq_fakequant_bwd.o')]
 HEADERS = ['bvq_common.h', 'bvq_quant_math.h', 'bvq_ties.h', 'bvq_sums.h', os.path.join(ROOT, 'include', 'bvq.h')]
 

@@ -729,92 +729,118 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
   uint32_t umax = 0;  // kBwdDsTies: largest |x| key this lane has seen in the unit's full chunks
   unsigned long long tie_first = ~0ull;
   f2 ds_acc2 = splat2(0.f), dzp_acc2 = splat2(0.f);  // pairwise path; folded into the scalars at the end
-  // Software-pipelined walk: the loads of chunk i + kD are issued BEFORE chunk i is worked on, so every wave
-  // keeps kD chunks of x and of g in flight while it computes (the counters of the round-1 kernel showed its
-  // waves 45 % of their time in arithmetic or waiting to issue with nothing in flight:
-  // profiles/r02/pmc_backward.md).  One chunk per step, so a 56x56 row (392 chunks) costs 7 steps of
-  // arithmetic instead of 4 x 2.
-  constexpr int kD = kBwdDepth;
+  // the work on one chunk (VEC elements of x and g -> VEC elements of dx, sums and the chunk's largest |x| key)
+  auto chunk = [&](const vec_t<XT, VEC>& xv, const vec_t<CT, VEC>& gv, int64_t off) {
+    vec_t<XT, VEC> dv;
+    if constexpr (VEC % 2 == 0) {
+#pragma unroll
+      for (int k = 0; k < VEC; k += 2) {
+        const f2 xraw = widen2<XT>(xv.v[k], xv.v[k + 1]);
+        constexpr bool kSame16 = sizeof(CT) == 2 && sizeof(XT) == 2;  // then XT is CT (dispatch pairs)
+        f2 d = bwd_elem2<CT, RM, MODE, ZP0, kSame16>(PRE ? relu2(xraw) : xraw, widen2<CT>(gv.v[k], gv.v[k + 1]),
+                                            div, s, z, qmin, qmax, clamp_ste, mode, ds_acc2, dzp_acc2);
+        if constexpr (PRE) d = xraw > splat2(0.f) ? d : splat2(0.f);  // torch.relu backward: grad * (x > 0)
+        pack2<XT>(d, dv.v[k], dv.v[k + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float xraw = to_f<XT>(xv.v[k]);
+        float d = bwd_elem<CT, RM, MODE, ZP0>(PRE ? relu_f(xraw) : xraw, to_f<CT>(gv.v[k]), div, s, z,
+                                              qmin, qmax, clamp_ste, mode, ds_acc, dzp_acc);
+        if constexpr (PRE) d = xraw > 0.f ? d : 0.f;  // torch.relu backward: grad * (x > 0)
+        dv.v[k] = from_f<XT>(d);
+      }
+    }
+    if constexpr (MODE == kBwdDsTies) {
+      // cheap chunk-level filter: a tie in this chunk needs the chunk's max |x| to reach the statistic
+      if constexpr (sizeof(XT) == 2 && VEC % 2 == 0 && !PRE) {
+        // two 16-bit keys per word: clear both sign bits, packed unsigned max (2 ops per pair)
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const vec_t<uint32_t, VEC / 2> w = __builtin_bit_cast(vec_t<uint32_t, VEC / 2>, xv);
+        u16x2 m2 = {0, 0};
+#pragma unroll
+        for (int k = 0; k < VEC / 2; ++k)
+          m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, w.v[k] & 0x7fff7fffu));
+        const uint32_t m16 = m2.x > m2.y ? m2.x : m2.y;
+        const uint32_t mx = elem<XT>::id == BVQ_BF16 ? (m16 << 16) : m16;  // the abs_bits<> key space
+        umax = mx > umax ? mx : umax;
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const uint32_t b = pre_abs_bits<XT, PRE>(xv.v[k]);
+          umax = b > umax ? b : umax;
+        }
+      }
+    }
+    store_vec<XT, VEC, NT>(dxp + off, dv);
+  };
   ChunkCursor cur;
   cur.init(u, VEC, lane);
   const int64_t total = (int64_t)u.nrows * cur.cpr;
-  const int32_t steps = (int32_t)((total + kWave - 1) / kWave);  // chunks per lane, the last possibly partial
-  vec_t<XT, VEC> xb[kD];
-  vec_t<CT, VEC> gb[kD];
-  int64_t offb[kD];
-  bool okb[kD];
+  if constexpr (elem<CT>::id == BVQ_F16) {
+    // float16: batches of two chunks per stream, loaded together, then worked on.  The guarded reciprocal's
+    // wave-wide checks (DivF16) make the pipelined form below 20 % SLOWER here (profiles/r02_backward_variants.txt).
+    constexpr int kU = 2;
+    for (int64_t done = 0; done < total; done += (int64_t)kWave * kU) {
+      vec_t<XT, VEC> xv[kU];
+      vec_t<CT, VEC> gv[kU];
+      int64_t off[kU];
+      bool ok[kU];
 #pragma unroll
-  for (int j = 0; j < kD; ++j) {
-    okb[j] = cur.valid();
-    offb[j] = cur.offset(u.row_stride, VEC);
-    if (j < steps) {  // wave-uniform
-      const int64_t lo = okb[j] ? offb[j] : 0;  // past the end: re-read the unit's first chunk
-      xb[j] = load_vec<XT, VEC, NTX>(xp + lo);
-      gb[j] = load_vec<CT, VEC, NT>(gp + lo);
+      for (int j = 0; j < kU; ++j) {
+        ok[j] = cur.valid();
+        off[j] = cur.offset(u.row_stride, VEC);
+        const int64_t lo = ok[j] ? off[j] : 0;  // past the end: re-read the unit's first chunk
+        xv[j] = load_vec<XT, VEC, NTX>(xp + lo);
+        gv[j] = load_vec<CT, VEC, NT>(gp + lo);
+        cur.next();
+      }
+#pragma unroll
+      for (int j = 0; j < kU; ++j)
+        if (ok[j]) chunk(xv[j], gv[j], off[j]);
     }
-    cur.next();
-  }
-  for (int32_t base = 0; base < steps; base += kD) {
+  } else {
+    // Software-pipelined walk: the loads of chunk i + kD are issued BEFORE chunk i is worked on, so every wave
+    // keeps kD chunks of x and of g in flight while it computes (the counters of the round-1 kernel showed its
+    // waves 45 % of their time in arithmetic or waiting to issue with nothing in flight:
+    // profiles/r02/pmc_backward.md).  One chunk per step, so a 56x56 row (392 chunks) costs 7 steps of
+    // arithmetic instead of 4 x 2.
+    constexpr int kD = kBwdDepth;
+    const int32_t steps = (int32_t)((total + kWave - 1) / kWave);  // chunks per lane, the last possibly partial
+    vec_t<XT, VEC> xb[kD];
+    vec_t<CT, VEC> gb[kD];
+    int64_t offb[kD];
+    bool okb[kD];
 #pragma unroll
     for (int j = 0; j < kD; ++j) {
-      if (base + j >= steps) break;  // wave-uniform
-      const vec_t<XT, VEC> xv = xb[j];
-      const vec_t<CT, VEC> gv = gb[j];
-      const int64_t off = offb[j];
-      const bool ok = okb[j];
-      // refill this slot with chunk base + j + kD
       okb[j] = cur.valid();
       offb[j] = cur.offset(u.row_stride, VEC);
-      if (base + j + kD < steps) {
-        const int64_t lo = okb[j] ? offb[j] : 0;
+      if (j < steps) {  // wave-uniform
+        const int64_t lo = okb[j] ? offb[j] : 0;  // past the end: re-read the unit's first chunk
         xb[j] = load_vec<XT, VEC, NTX>(xp + lo);
         gb[j] = load_vec<CT, VEC, NT>(gp + lo);
       }
       cur.next();
-      if (ok) {
-        vec_t<XT, VEC> dv;
-        if constexpr (VEC % 2 == 0) {
+    }
+    for (int32_t base = 0; base < steps; base += kD) {
 #pragma unroll
-          for (int k = 0; k < VEC; k += 2) {
-            const f2 xraw = widen2<XT>(xv.v[k], xv.v[k + 1]);
-            constexpr bool kSame16 = sizeof(CT) == 2 && sizeof(XT) == 2;  // then XT is CT (dispatch pairs)
-            f2 d = bwd_elem2<CT, RM, MODE, ZP0, kSame16>(PRE ? relu2(xraw) : xraw, widen2<CT>(gv.v[k], gv.v[k + 1]),
-                                                div, s, z, qmin, qmax, clamp_ste, mode, ds_acc2, dzp_acc2);
-            if constexpr (PRE) d = xraw > splat2(0.f) ? d : splat2(0.f);  // torch.relu backward: grad * (x > 0)
-            pack2<XT>(d, dv.v[k], dv.v[k + 1]);
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) {
-            const float xraw = to_f<XT>(xv.v[k]);
-            float d = bwd_elem<CT, RM, MODE, ZP0>(PRE ? relu_f(xraw) : xraw, to_f<CT>(gv.v[k]), div, s, z,
-                                                  qmin, qmax, clamp_ste, mode, ds_acc, dzp_acc);
-            if constexpr (PRE) d = xraw > 0.f ? d : 0.f;  // torch.relu backward: grad * (x > 0)
-            dv.v[k] = from_f<XT>(d);
-          }
+      for (int j = 0; j < kD; ++j) {
+        if (base + j >= steps) break;  // wave-uniform
+        const vec_t<XT, VEC> xv = xb[j];
+        const vec_t<CT, VEC> gv = gb[j];
+        const int64_t off = offb[j];
+        const bool ok = okb[j];
+        // refill this slot with chunk base + j + kD
+        okb[j] = cur.valid();
+        offb[j] = cur.offset(u.row_stride, VEC);
+        if (base + j + kD < steps) {
+          const int64_t lo = okb[j] ? offb[j] : 0;
+          xb[j] = load_vec<XT, VEC, NTX>(xp + lo);
+          gb[j] = load_vec<CT, VEC, NT>(gp + lo);
         }
-        if constexpr (MODE == kBwdDsTies) {
-          // cheap chunk-level filter: a tie in this chunk needs the chunk's max |x| to reach the statistic
-          if constexpr (sizeof(XT) == 2 && VEC % 2 == 0 && !PRE) {
-            // two 16-bit keys per word: clear both sign bits, packed unsigned max (2 ops per pair)
-            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-            const vec_t<uint32_t, VEC / 2> w = __builtin_bit_cast(vec_t<uint32_t, VEC / 2>, xv);
-            u16x2 m2 = {0, 0};
-#pragma unroll
-            for (int k = 0; k < VEC / 2; ++k)
-              m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, w.v[k] & 0x7fff7fffu));
-            const uint32_t m16 = m2.x > m2.y ? m2.x : m2.y;
-            const uint32_t mx = elem<XT>::id == BVQ_BF16 ? (m16 << 16) : m16;  // the abs_bits<> key space
-            umax = mx > umax ? mx : umax;
-          } else {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-              const uint32_t b = pre_abs_bits<XT, PRE>(xv.v[k]);
-              umax = b > umax ? b : umax;
-            }
-          }
-        }
-        store_vec<XT, VEC, NT>(dxp + off, dv);
+        cur.next();
+        if (ok) chunk(xv, gv, off);
       }
     }
   }

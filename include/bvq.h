@@ -419,6 +419,44 @@ int bvq_fakequant_bwd_stats(const bvq_quant_desc* desc, const void* g, const voi
                             double int_threshold, int quot_dtype, void* workspace, int64_t workspace_bytes,
                             bvq_stream_t stream);
 
+/* ---- the other quantizers of the family -------------------------------------------
+ * BinaryQuant / ClampedBinaryQuant (B/core/quant/binary.py:19-101), TernaryQuant (B/core/quant/ternary.py:18-66),
+ * DecoupledIntQuant (B/core/quant/int_base.py:100-182) and TruncIntQuant (B/core/quant/int.py:199-229) as ONE
+ * forward kernel (read x, write y) and ONE backward kernel (read g, read x, write dx; the scale gradients as
+ * float32 sums over the tensor or per channel) instead of the reference's 4..10 torch ops each, with the
+ * reference's rounding points in the compute dtype ct_dtype = torch.result_type of its op chain.
+ *   x viewed as [outer, channels, inner]; scale / pre_scale: 1 element (whole tensor) or `channels` elements in
+ *   scale_dtype; zero-points: ONE element in zp_dtype, or null for +0.  kind-specific fields:
+ *     BINARY          y = binary_sign(x) * scale
+ *     CLAMPED_BINARY  x clamped to [-scale, scale] first; clamp_ste = 0: the clamp masks dx and feeds d(scale)
+ *     TERNARY         y = [|x| > threshold * scale] * sign(x) * scale   (ct_dtype must be float32: the reference's
+ *                     mask.float() promotes)
+ *     DECOUPLED       round_mode / qmin / qmax / clamp_ste as bvq_quant_desc; rounding grid from (pre_scale, pre_zp),
+ *                     de-quantization with (scale, zp); dpre_scale receives the pre-scale's gradient
+ *     TRUNC           y = (round_mode(round((x / scale + zp)) / trunc_scale) - zp) * scale
+ * dscale / dpre_scale: float32 [1 or channels], nullable.  Workspace: bvq_variant_bwd_workspace_bytes. */
+typedef enum bvq_variant_kind {
+  BVQ_VAR_BINARY = 0, BVQ_VAR_CLAMPED_BINARY = 1, BVQ_VAR_TERNARY = 2, BVQ_VAR_DECOUPLED = 3, BVQ_VAR_TRUNC = 4
+} bvq_variant_kind;
+typedef struct bvq_variant_desc {
+  int64_t outer, channels, inner;
+  int32_t kind;               /* bvq_variant_kind */
+  int32_t x_dtype, ct_dtype, scale_dtype, zp_dtype;
+  int32_t scale_per_channel;
+  int32_t round_mode;         /* bvq_round_mode */
+  int32_t clamp_ste;
+  int32_t scalar_mode;        /* bvq_scalar_mode */
+  float qmin, qmax;           /* DECOUPLED */
+  float threshold;            /* TERNARY */
+  float trunc_scale;          /* TRUNC: 2^(input_bit_width - output_bit_width) */
+} bvq_variant_desc;
+int bvq_variant_fwd(const bvq_variant_desc* desc, const void* x, const void* scale, const void* pre_scale,
+                    const void* zp, const void* pre_zp, void* y, bvq_stream_t stream);
+int64_t bvq_variant_bwd_workspace_bytes(const bvq_variant_desc* desc);
+int bvq_variant_bwd(const bvq_variant_desc* desc, const void* g, const void* x, const void* scale,
+                    const void* pre_scale, const void* zp, const void* pre_zp, void* dx, float* dscale,
+                    float* dpre_scale, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

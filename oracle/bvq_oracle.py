@@ -33,6 +33,19 @@ class QuantDesc(ctypes.Structure):
         ('out_kind', ctypes.c_int32), ('pre_op', ctypes.c_int32), ('codes_dtype', ctypes.c_int32)]
 
 
+class VariantDesc(ctypes.Structure):
+    """bvq_variant_desc of include/bvq.h"""
+    _fields_ = [
+        ('outer', ctypes.c_int64), ('channels', ctypes.c_int64), ('inner', ctypes.c_int64), ('kind', ctypes.c_int32),
+        ('x_dtype', ctypes.c_int32), ('ct_dtype', ctypes.c_int32), ('scale_dtype', ctypes.c_int32),
+        ('zp_dtype', ctypes.c_int32), ('scale_per_channel', ctypes.c_int32), ('round_mode', ctypes.c_int32),
+        ('clamp_ste', ctypes.c_int32), ('scalar_mode', ctypes.c_int32), ('qmin', ctypes.c_float),
+        ('qmax', ctypes.c_float), ('threshold', ctypes.c_float), ('trunc_scale', ctypes.c_float)]
+
+
+VAR_BINARY, VAR_CLAMPED_BINARY, VAR_TERNARY, VAR_DECOUPLED, VAR_TRUNC = range(5)
+
+
 def build(force=False):
     src = os.path.join(_HERE, 'bvq_oracle.c')
     hdr = os.path.join(_HERE, '..', 'include', 'bvq.h')
@@ -215,6 +228,32 @@ def fakequant_bwd(desc, g, x, scale, zp):
     lib().orc_fakequant_bwd(ctypes.byref(desc), _ptr(g), _ptr(x), _ptr(scale), _ptr(zp), _ptr(dx),
                             _ptr(ds), _ptr(dz))
     return dx, ds, dz
+
+
+def variant_fwd(desc, x, scale, pre_scale=None, zp=None, pre_zp=None):
+    """BinaryQuant / ClampedBinaryQuant / TernaryQuant / DecoupledIntQuant / TruncIntQuant forward -> y (ct dtype)"""
+    x = _c(x, desc.x_dtype)
+    y = np.empty(x.shape, dtype=np_dtype(desc.ct_dtype))
+    lib().orc_variant_fwd(ctypes.byref(desc), _ptr(x), _ptr(_c(scale, desc.scale_dtype)),
+                          _ptr(_c(pre_scale, desc.scale_dtype)) if pre_scale is not None else None,
+                          _ptr(_c(zp, desc.zp_dtype)) if zp is not None else None,
+                          _ptr(_c(pre_zp, desc.zp_dtype)) if pre_zp is not None else None, _ptr(y))
+    return y
+
+
+def variant_bwd(desc, g, x, scale, pre_scale=None, zp=None, pre_zp=None):
+    """-> (dx, dscale float32, dpre_scale float32)"""
+    x = _c(x, desc.x_dtype)
+    g = _c(g, desc.ct_dtype)
+    nsum = desc.channels if (desc.scale_per_channel and desc.channels > 1) else 1
+    dx = np.empty(x.shape, dtype=np_dtype(desc.x_dtype))
+    ds = np.empty(nsum, dtype=np.float32)
+    dp = np.empty(nsum, dtype=np.float32)
+    lib().orc_variant_bwd(ctypes.byref(desc), _ptr(g), _ptr(x), _ptr(_c(scale, desc.scale_dtype)),
+                          _ptr(_c(pre_scale, desc.scale_dtype)) if pre_scale is not None else None,
+                          _ptr(_c(zp, desc.zp_dtype)) if zp is not None else None,
+                          _ptr(_c(pre_zp, desc.zp_dtype)) if pre_zp is not None else None, _ptr(dx), _ptr(ds), _ptr(dp))
+    return dx, ds, dp
 
 
 def step_stats_scaled(desc, x, g, min_val, int_threshold):

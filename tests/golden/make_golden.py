@@ -589,7 +589,7 @@ def gen_variants():
     from brevitas.core.quant import (BinaryQuant, ClampedBinaryQuant, DecoupledIntQuant, TernaryQuant,
                                      TruncIntQuant)
     st = Store('variants')
-    for dn in ('f32', 'bf16'):
+    for dn in ('f32', 'bf16', 'f16'):
         x = (torch.randn(5, 7, 3) * 0.8).to(DT[dn])
         x.view(-1)[::11] = 0.0
         for name, mk in (('binary', lambda: BinaryQuant(ParameterScaling(0.7))),
@@ -620,6 +620,30 @@ def gen_variants():
             g = torch.randn(y.shape).to(y.dtype)
             y.backward(g)
             st.case({'quant': 'trunc', 'round': rm, 'dtype': dn}, x=xq, g=g, y=y, dx=xi.grad, scale=so, bit_width=bo)
+        # per-channel scales (dimensioned, in the tensor's dtype) and the straight-through clamp
+        xw = (torch.randn(6, 40) * 0.8).to(DT[dn])
+        for name, mk in (('binary', lambda: BinaryQuant(ParameterScaling(torch.rand(6, 1) + 0.3, (6, 1)))),
+                         ('clamped_binary', lambda: ClampedBinaryQuant(ParameterScaling(torch.rand(6, 1) + 0.3, (6, 1)),
+                                                                      tensor_clamp_impl=TensorClampSte())),
+                         ('ternary', lambda: TernaryQuant(ParameterScaling(torch.rand(6, 1) + 0.3, (6, 1)), 0.6))):
+            q = mk().to(DT[dn])
+            xi = xw.clone().requires_grad_(True)
+            y, scale, zp, bwt = q(xi)
+            g = torch.randn(y.shape).to(y.dtype)
+            y.backward(g)
+            st.case({'quant': name, 'dtype': dn, 'tag': 'per_channel'}, x=xw, g=g, y=y, scale=scale, zp=zp,
+                    bit_width=bwt, dx=xi.grad, dvalue=q.scaling_impl.value.grad,
+                    value=q.scaling_impl.value.detach().clone())
+        # decoupled with learnable scales: gradients of pre_scale and scale, per channel, non-zero zero-points
+        dq = DecoupledIntQuant(narrow_range=False, signed=True, tensor_clamp_impl=TensorClamp())
+        xi = xw.clone().requires_grad_(True)
+        pre_scale = (torch.rand(6, 1) * 0.05 + 0.02).to(DT[dn]).requires_grad_(True)
+        scale = (torch.rand(6, 1) * 0.05 + 0.02).to(DT[dn]).requires_grad_(True)
+        y = dq(pre_scale, torch.tensor(1.), scale, torch.tensor(2.), torch.tensor(4.), xi)
+        g = torch.randn(y.shape).to(y.dtype)
+        y.backward(g)
+        st.case({'quant': 'decoupled', 'dtype': dn, 'tag': 'per_channel'}, x=xw, g=g, y=y, dx=xi.grad,
+                pre_scale=pre_scale.detach(), scale=scale.detach(), dpre_scale=pre_scale.grad, dscale=scale.grad)
     # doctests: B/core/quant/int_base.py:118-126, ternary.py:32-44
     inp = torch.Tensor([0.042, -0.053, 0.31, -0.44])
     y = DecoupledIntQuant(narrow_range=True, signed=True)(torch.tensor(0.02), torch.tensor(0.), torch.tensor(0.01),

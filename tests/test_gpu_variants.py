@@ -1,78 +1,143 @@
-"""Quantizer variants of the same elementwise family: binary, clamped binary,
-ternary, decoupled and truncating quantizers against the reference (tests/golden/variants.npz).
-They run op by op on the HIP-backed straight-through ops: y and dx bit-exact."""
+"""Quantizer variants of the same elementwise family: binary, clamped binary, ternary,
+decoupled and truncating quantizers against the reference (tests/golden/variants.npz: float32, bfloat16 and float16;
+0-dim learned scales and per-channel ones, plain and straight-through clamps, non-zero zero-points, gradients of
+both decoupled scales).  On a device tensor each runs as ONE forward kernel and ONE backward kernel
+(include/bvq.h, bvq_variant_fwd / bvq_variant_bwd): y and dx bit-exact, scale gradients within the rounding of a
+reduced sum (the reference rounds every product and the running sum to the tensor dtype)."""
 import numpy as np
 import pytest
 import torch
 
 import golden_util as G
-from test_gpu_modules import assert_bits
+from test_gpu_modules import SUM_RTOL, assert_bits
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 CASES = G.load('variants')
+DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}
+
+
+@pytest.fixture(autouse=True)
+def cpu_scalar_semantics(monkeypatch):
+    """the golden vectors come from torch CPU kernels, which keep a 0-dim float32 scale next to a 16-bit tensor in
+    float32 (include/bvq.h, bvq_scalar_mode)"""
+    import brevitas_amd.config as config
+    monkeypatch.setattr(config, 'SCALAR_OPERAND_MODE', 'cpu')
 
 
 def pick(name):
     return [c for c in CASES if c['quant'] == name]
 
 
+def assert_sum(got, c, name, terms):
+    """a gradient that is a sum of rounded products: the reference rounds every product AND the running sum to the
+    tensor dtype (the dtype of dx), whatever dtype the parameter that receives the sum has"""
+    want = c.f32(name).reshape(-1)
+    got = got.detach().float().cpu().numpy().reshape(-1)
+    tol = SUM_RTOL[c['dtypes']['dx']] * (np.abs(want) * 4 + terms)
+    assert np.all(np.abs(got - want) <= tol), (name, got, want, tol)
+
+
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'generic'])
 @pytest.mark.parametrize('c', pick('binary') + pick('clamped_binary') + pick('ternary'),
-                         ids=lambda c: '%s-%s' % (c['quant'], c['dtype']))
-def test_sign_quantizers(c):
+                         ids=lambda c: '%s-%s-%s' % (c['quant'], c['dtype'], c.get('tag')))
+def test_sign_quantizers(c, fused, monkeypatch):
+    import brevitas_amd.config as config
+    from brevitas_amd.core.function_wrapper import TensorClampSte
     from brevitas_amd.core.quant import BinaryQuant, ClampedBinaryQuant, TernaryQuant
     from brevitas_amd.core.scaling import ParameterScaling
-    q = {'binary': lambda: BinaryQuant(ParameterScaling(0.7)),
-         'clamped_binary': lambda: ClampedBinaryQuant(ParameterScaling(0.7)),
-         'ternary': lambda: TernaryQuant(ParameterScaling(0.9), 0.5)}[c['quant']]().to(DEV)
+    monkeypatch.setattr(config, 'FUSED_PATHS', fused)
+    if c.get('tag') == 'per_channel':
+        v = c.torch('value')
+        q = {'binary': lambda: BinaryQuant(ParameterScaling(v, tuple(v.shape))),
+             'clamped_binary': lambda: ClampedBinaryQuant(ParameterScaling(v, tuple(v.shape)),
+                                                          tensor_clamp_impl=TensorClampSte()),
+             'ternary': lambda: TernaryQuant(ParameterScaling(v, tuple(v.shape)), 0.6)}[c['quant']]().to(DT[c['dtype']])
+    else:
+        q = {'binary': lambda: BinaryQuant(ParameterScaling(0.7)),
+             'clamped_binary': lambda: ClampedBinaryQuant(ParameterScaling(0.7)),
+             'ternary': lambda: TernaryQuant(ParameterScaling(0.9), 0.5)}[c['quant']]()
+    q = q.to(DEV)
     x = c.torch('x', DEV).requires_grad_(True)
     y, scale, zp, bw = q(x)
+    if not fused and c['dtype'] != 'f32' and c.get('tag') != 'per_channel':
+        # op by op on the device, torch rounds a 0-dim float32 scale to the tensor dtype first: one ulp at most
+        assert bool(((y.float().cpu() - c.torch('y').float()).abs() <= 2.0 ** -7 * c.torch('y').float().abs()).all())
+        return
     assert_bits(y, c, 'y')
     assert_bits(scale, c, 'scale')
     assert float(zp) == float(c.f32('zp')) and float(bw) == float(c.f32('bit_width'))
     y.backward(c.torch('g', DEV))
-    if c['dtype'] == 'f32':
-        assert_bits(x.grad, c, 'dx')
-    else:
-        # dx = g * scale with a 0-dim float32 scale next to a bf16 tensor: torch's device kernels round
-        # the scalar to bf16 first, the CPU kernels (golden) do not -- one bf16 ulp apart at most
-        got, ref = x.grad.float().cpu(), c.torch('dx').float()
-        assert bool(((got - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-30).all())
-    want = c.f32('dvalue').reshape(-1)
-    got = q.scaling_impl.value.grad.float().cpu().numpy().reshape(-1)
-    np.testing.assert_allclose(got, want, rtol=2e-2 if c['dtype'] == 'bf16' else 1e-5, atol=1e-6)
+    assert_bits(x.grad, c, 'dx')
+    per_sum = x.numel() // q.scaling_impl.value.numel()
+    assert_sum(q.scaling_impl.value.grad, c, 'dvalue', np.sqrt(per_sum) * float(np.abs(c.f32('g')).max()))
 
 
-@pytest.mark.parametrize('c', pick('decoupled'), ids=lambda c: c['dtype'])
-def test_decoupled(c):
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'generic'])
+@pytest.mark.parametrize('c', pick('decoupled'), ids=lambda c: '%s-%s' % (c['dtype'], c.get('tag')))
+def test_decoupled(c, fused, monkeypatch):
+    import brevitas_amd.config as config
+    from brevitas_amd.core.bit_width import BitWidthConst
+    from brevitas_amd.core.function_wrapper import TensorClamp
     from brevitas_amd.core.quant import DecoupledIntQuant
-    dq = DecoupledIntQuant(narrow_range=True, signed=True).to(DEV)
+    monkeypatch.setattr(config, 'FUSED_PATHS', fused)
     x = c.torch('x', DEV).requires_grad_(True)
     t = lambda v: torch.tensor(v, device=DEV)  # noqa: E731
-    y = dq(c.torch('pre_scale', DEV), t(0.), c.torch('scale', DEV), t(0.), t(4.), x)
-    if c['dtype'] == 'f32':
-        assert_bits(y, c, 'y')
-        y.backward(c.torch('g', DEV))
-        assert_bits(x.grad, c, 'dx')
-    else:  # 0-dim float32 scales next to a bf16 tensor: torch's device kernels round them to bf16 first
-        assert torch.allclose(y.float().cpu(), c.torch('y').float(), atol=0.02)
+    bw = BitWidthConst(4).to(DEV)()
+    if c.get('tag') == 'per_channel':
+        dq = DecoupledIntQuant(narrow_range=False, signed=True, tensor_clamp_impl=TensorClamp()).to(DEV)
+        pre_scale = c.torch('pre_scale', DEV).requires_grad_(True)
+        scale = c.torch('scale', DEV).requires_grad_(True)
+        y = dq(pre_scale, t(1.), scale, t(2.), bw, x)
+    else:
+        dq = DecoupledIntQuant(narrow_range=True, signed=True).to(DEV)
+        pre_scale, scale = c.torch('pre_scale', DEV), c.torch('scale', DEV)
+        y = dq(pre_scale, t(0.), scale, t(0.), bw, x)
+    if not fused and c['dtype'] != 'f32' and c.get('tag') != 'per_channel':
+        assert torch.allclose(y.float().cpu(), c.torch('y').float(), atol=0.02)  # 0-dim scales, device rounding
+        return
+    assert_bits(y, c, 'y')
+    y.backward(c.torch('g', DEV))
+    assert_bits(x.grad, c, 'dx')
+    if c.get('tag') == 'per_channel':
+        terms = np.sqrt(x.shape[1]) * float(np.abs(c.f32('g')).max()) * 16
+        assert_sum(scale.grad, c, 'dscale', terms)
+        assert_sum(pre_scale.grad, c, 'dpre_scale', terms * 64)
 
 
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'generic'])
 @pytest.mark.parametrize('c', pick('trunc'), ids=lambda c: '%s-%s' % (c['round'], c['dtype']))
-def test_trunc(c):
+def test_trunc(c, fused, monkeypatch):
+    import brevitas_amd.config as config
     from brevitas_amd.core.bit_width import BitWidthConst
     from brevitas_amd.core.function_wrapper import FloorSte, RoundSte
     from brevitas_amd.core.quant import TruncIntQuant
+    monkeypatch.setattr(config, 'FUSED_PATHS', fused)
     tq = TruncIntQuant({'floor': FloorSte, 'round': RoundSte}[c['round']](), BitWidthConst(5)).to(DEV)
     x = c.torch('x', DEV).requires_grad_(True)
-    y, scale, zp, bw = tq(x, torch.tensor(0.05, device=DEV), torch.tensor(0., device=DEV), torch.tensor(8., device=DEV))
+    in_bw = BitWidthConst(8).to(DEV)()  # a constant bit width handed on by the previous layer: known on the host
+    y, scale, zp, bw = tq(x, torch.tensor(0.05, device=DEV), torch.tensor(0., device=DEV), in_bw)
     assert float(bw) == 5.0
-    if c['dtype'] == 'f32':
-        assert_bits(y, c, 'y')
-        y.backward(c.torch('g', DEV))
-        assert_bits(x.grad, c, 'dx')
-    else:
-        assert torch.allclose(y.float().cpu(), c.torch('y').float(), atol=0.06)
+    if not fused and c['dtype'] != 'f32':
+        assert torch.allclose(y.float().cpu(), c.torch('y').float(), atol=0.06)  # 0-dim scale, device rounding
+        return
+    assert_bits(y, c, 'y')
+    y.backward(c.torch('g', DEV))
+    assert_bits(x.grad, c, 'dx')
+
+
+def test_variant_kernels_are_the_route_taken(monkeypatch):
+    """a device tensor with covered operands must run the fused kernels, not the op-by-op composition"""
+    from brevitas_amd import _native as nat
+    from brevitas_amd.core.quant import BinaryQuant, TernaryQuant
+    from brevitas_amd.core.scaling import ParameterScaling
+    calls = []
+    real = nat.variant_fwd
+    monkeypatch.setattr(nat, 'variant_fwd', lambda *a, **k: (calls.append(a[0].kind), real(*a, **k))[1])
+    x = torch.randn(4, 33, device=DEV)
+    BinaryQuant(ParameterScaling(0.5)).to(DEV)(x)
+    TernaryQuant(ParameterScaling(0.5), 0.5).to(DEV)(x.to(torch.bfloat16))
+    assert calls == [nat.VAR_BINARY, nat.VAR_TERNARY]
 
 
 def test_doctests():
