@@ -38,7 +38,8 @@ EXPORTS = (
     'bvq_abs_affine_bwd', 'bvq_kth_workspace_bytes', 'bvq_kth_value', 'bvq_kth_pair', 'bvq_kth_passes',
     'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd',
     'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd_stats_workspace_bytes', 'bvq_fakequant_bwd_stats', 'bvq_fakequant_bwd',
-    'bvq_learned_scale', 'bvq_fakequant_bwd_learned', 'bvq_variant_fwd', 'bvq_variant_bwd_workspace_bytes', 'bvq_variant_bwd')
+    'bvq_learned_scale', 'bvq_fakequant_bwd_learned', 'bvq_variant_fwd', 'bvq_variant_bwd_workspace_bytes', 'bvq_variant_bwd',
+    'bvq_fakequant_fwd_bounds', 'bvq_fakequant_bwd_bounds', 'bvq_histc')
 
 
 class QuantDesc(ctypes.Structure):
@@ -118,6 +119,9 @@ def _load(path=None, strict=True):
         'bvq_stat_tie_apply_dscale': (i32, [i32, i32, vp, vp, vp, i32, dbl, i32, vp, vp, vp, i64, i64, i64, vp]),
         'bvq_fakequant_bwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
         'bvq_learned_scale': (i32, [i32, vp, i64, dbl, i32, dbl, i32, vp, vp]),
+        'bvq_histc': (i32, [i32, vp, i64, vp, i32, vp, vp]),
+        'bvq_fakequant_fwd_bounds': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp]),
+        'bvq_fakequant_bwd_bounds': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
         'bvq_variant_fwd': (i32, [ctypes.POINTER(VariantDesc), vp, vp, vp, vp, vp, vp, vp]),
         'bvq_variant_bwd_workspace_bytes': (i64, [ctypes.POINTER(VariantDesc)]),
         'bvq_variant_bwd': (i32, [ctypes.POINTER(VariantDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
@@ -644,6 +648,46 @@ def variant_bwd(desc, g, x, scale, pre_scale=None, zp=None, pre_zp=None, need_ds
         check(lib.bvq_variant_bwd(ctypes.byref(desc), ptr(g), ptr(x), ptr(scale), ptr(pre_scale), ptr(zp), ptr(pre_zp),
                                   ptr(dx), ptr(ds), ptr(dp), ptr(ws), wsb, stream_ptr(dev)), 'bvq_variant_bwd')
     return dx, ds, dp
+
+
+def fakequant_fwd_bounds(desc, x, scale, zp, bounds):
+    """bvq_fakequant_fwd with the integer range [qmin, qmax] read from the device (float32 [2]) -> y"""
+    dev = require_device(x, scale, zp, bounds)
+    assert bounds.dtype == torch.float32 and bounds.numel() == 2 and bounds.is_contiguous()
+    ct = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[desc.ct_dtype]
+    y = torch.empty(x.shape, dtype=ct, device=dev)
+    with _DeviceGuard(dev):
+        check(lib.bvq_fakequant_fwd_bounds(ctypes.byref(desc), ptr(x), ptr(scale), ptr(zp), ptr(bounds), ptr(y),
+                                           stream_ptr(dev)), 'bvq_fakequant_fwd_bounds')
+    return y
+
+
+def fakequant_bwd_bounds(desc, g, x, scale, zp, bounds, need_dbounds):
+    """-> (dx, dscale float32 [n], dbounds float32 [2, n] or None): n = channels or 1"""
+    dev = require_device(g, x, scale, zp, bounds)
+    dx = torch.empty_like(x)
+    nsum = int(desc.channels) if (desc.scale_per_channel and desc.channels > 1) else 1
+    ds = torch.empty(nsum, dtype=torch.float32, device=dev)
+    db = torch.empty(2, nsum, dtype=torch.float32, device=dev) if need_dbounds else None
+    wsb = int(lib.bvq_fakequant_bwd_workspace_bytes(ctypes.byref(desc)))
+    if wsb < 0:
+        raise BvqError('bvq_fakequant_bwd_workspace_bytes: ' + last_error())
+    ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
+    with _DeviceGuard(dev):
+        check(lib.bvq_fakequant_bwd_bounds(ctypes.byref(desc), ptr(g), ptr(x), ptr(scale), ptr(zp), ptr(bounds), ptr(dx),
+                                           ptr(ds), ptr(db), ptr(ws), wsb, stream_ptr(dev)), 'bvq_fakequant_bwd_bounds')
+    return dx, ds, db
+
+
+def histc(x, absmax, bins):
+    """torch.histc(x, bins, min=-absmax, max=absmax) with the bounds read from the device -> int32 [bins]"""
+    dev = require_device(x, absmax)
+    x = x.contiguous()
+    counts = torch.empty(bins, dtype=torch.int32, device=dev)
+    with _DeviceGuard(dev):
+        check(lib.bvq_histc(dtype_code(x.dtype), ptr(x), x.numel(), ptr(absmax.to(x.dtype).reshape(1)), int(bins),
+                            ptr(counts), stream_ptr(dev)), 'bvq_histc')
+    return counts
 
 
 def learned_scale(value, min_val, int_threshold, scale_dtype):

@@ -166,6 +166,44 @@ class FakeQuantFn(Function):
         return dx, ds, dz, None, None, None, None, None, None, None
 
 
+class FakeQuantBoundsFn(Function):
+    """IntQuant.forward whose integer range is a pair of 0-dim TENSORS (a learned bit width: min_int / max_int of the
+    bit-width tensor, B/core/bit_width/parameter.py:23-100, B/function/ops.py:132-191): the fused kernels read the
+    bounds from device memory, and the backward returns, next to dx and dscale, the gradient tensor_clamp's two
+    torch.where send to the bounds (plain TensorClamp only; a straight-through clamp gives the bounds none)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, zp, qmin_t, qmax_t, p, round_mode, clamp_ste, pre_op):
+        xc, back = _memory_order(x, p.channels, p.nhwc)
+        sc = scale.reshape(-1).contiguous()
+        zc = zp.reshape(-1).contiguous()
+        bounds = torch.stack([qmin_t.detach().reshape(()), qmax_t.detach().reshape(())]).float()
+        desc = make_desc(p, xc, sc, zc, 0.0, 0.0, round_mode, clamp_ste, nat.OUT_DEQUANT, pre_op)
+        y = nat.fakequant_fwd_bounds(desc, xc, sc, zc, bounds)
+        ctx.desc, ctx.back = desc, back
+        ctx.save_for_backward(xc, scale, zp, bounds, qmin_t, qmax_t)
+        return y if back is None else y.permute(back)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, scale, zp, bounds, qmin_t, qmax_t = ctx.saved_tensors
+        desc = ctx.desc
+        ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
+        gy = _like_memory_order(gy.to(ct), ctx.back)
+        need_db = (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) and not desc.clamp_ste
+        dx, ds, db = nat.fakequant_bwd_bounds(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1).contiguous(),
+                                              bounds, need_db)
+        dx = _restore(dx, ctx.back) if ctx.needs_input_grad[0] else None
+        ds = _reduce_like(ds, scale) if ctx.needs_input_grad[1] else None
+        dmin = dmax = None
+        if need_db:
+            # the reference sums where()'s masked gradient in the clamp's dtype, then casts to the bound's
+            sums = db.sum(dim=1).to(ct)
+            dmin = sums[0].to(qmin_t.dtype).reshape(qmin_t.shape) if ctx.needs_input_grad[3] else None
+            dmax = sums[1].to(qmax_t.dtype).reshape(qmax_t.shape) if ctx.needs_input_grad[4] else None
+        return dx, ds, None, dmin, dmax, None, None, None, None
+
+
 class LearnedScaleFakeQuantFn(Function):
     """scale = |clamp_min(value, min_val)| / int_threshold  ->  IntQuant with that scale and a zero zero-point:
     the steady state of the learned-scale activation quantizers (ParameterScaling, and

@@ -6,6 +6,8 @@ width is host-known, the whole chain  x/scale + zp -> round -> clamp -> (. - zp)
 ONE HIP kernel (and its autograd as one more); anything else runs the same chain op by op through
 the HIP-backed straight-through ops, exactly as the reference composes it.
 """
+from typing import NamedTuple, Optional
+
 import torch
 from torch import Tensor
 from torch.nn import Module
@@ -16,6 +18,22 @@ from brevitas_amd.core.function_wrapper import RoundSte, TensorClamp
 from brevitas_amd.core.quant import _fused
 from brevitas_amd.core.quant.delay import DelayWrapper, _NoDelay
 from brevitas_amd.function.ops import int_range_host, max_int, min_int
+
+
+class QCDQOperands(NamedTuple):
+    """what QuantizeLinear -> Clip -> DequantizeLinear consume (IntQuant.to_qcdq_operands)"""
+    int_codes: Tensor      # int8 / uint8 (up to 8 bits) or int32, shape of x
+    scale: Tensor          # 0-dim or [channels]
+    zero_point: Tensor     # dtype of int_codes, shape of scale
+    axis: Optional[int]    # channel axis of a per-channel scale, None for per-tensor
+
+    def dequantize(self) -> Tensor:
+        """DequantizeLinear: (codes - zero_point) * scale along `axis` (B/export/common/handler/qcdq.py:26-27)"""
+        shape = [1] * self.int_codes.dim()
+        if self.axis is not None:
+            shape[self.axis] = -1
+        return (self.int_codes.to(self.scale.dtype) - self.zero_point.to(self.scale.dtype).reshape(shape)) \
+            * self.scale.reshape(shape)
 
 
 class IntQuant(torch.nn.Module):
@@ -106,6 +124,23 @@ class IntQuant(torch.nn.Module):
         codes = nat.fakequant_fwd(desc, xc, sc, zc, want_codes=True, want_y=False)
         return codes if back is None else codes.permute(back)
 
+    def to_qcdq_operands(self, scale: Tensor, zero_point: Tensor, bit_width: Tensor, x: Tensor) -> 'QCDQOperands':
+        """The operand package of a QuantizeLinear / Clip / DequantizeLinear chain, as the reference's QCDQ export
+        handlers assemble it (B/export/common/handler/qcdq.py:92-150, base.py:34-41,125-139): integer codes in the
+        wire dtype (written directly by the quantizer kernel, to_int_codes), the scale flattened (0-dim if it has one
+        element), the zero-point expanded like the scale and cast to the codes' dtype, and the quantization axis (the
+        first dim of the scale that is not 1, None for a per-tensor scale).  Not differentiable."""
+        codes = self.to_int_codes(scale, zero_point, bit_width, x)
+        axis = next((i for i, s in enumerate(scale.shape) if s != 1), None)
+        flat = scale.detach().flatten()
+        sc = flat.view(()) if flat.numel() == 1 else flat
+        zf = zero_point.detach().flatten()
+        zf = zf.view(()) if zf.numel() == 1 else zf
+        zf = zf.expand_as(sc)
+        if not self.signed and bool((zf < 0).any()):
+            raise RuntimeError("Zero points have to be positive under unsigned quantization")
+        return QCDQOperands(codes, sc, zf.to(codes.dtype), axis)
+
     def min_int(self, bit_width):
         return min_int(self.signed, self.narrow_range, bit_width)
 
@@ -128,11 +163,35 @@ class IntQuant(torch.nn.Module):
             if pre_op != nat.PRE_NONE and not isinstance(self.delay_wrapper.delay_impl, _NoDelay):
                 x_act = torch.relu(x)
         else:
+            bounds = self._fused_bounds_args(scale, zero_point, bit_width, x)
+            if bounds is not None:
+                # a bit width that is a tensor in the autograd graph (learned): the same kernels with the integer
+                # range read from device memory, the range's own gradient returned next to dx and dscale
+                p, round_mode, clamp_ste = bounds
+                y = _fused.FakeQuantBoundsFn.apply(x, scale, zero_point, self.min_int(bit_width),
+                                                   self.max_int(bit_width), p, round_mode, clamp_ste, pre_op)
+                x_act = x
+                if pre_op != nat.PRE_NONE and not isinstance(self.delay_wrapper.delay_impl, _NoDelay):
+                    x_act = torch.relu(x)
+                return self.delay_wrapper(x_act, y)
             x_act = torch.relu(x) if pre_op == nat.PRE_RELU else x
             y_int = self.to_int(scale, zero_point, bit_width, x_act)
             y = y_int - zero_point
             y = y * scale
         return self.delay_wrapper(x_act, y)
+
+    def _fused_bounds_args(self, scale: Tensor, zero_point: Tensor, bit_width: Tensor, x: Tensor):
+        """(plan, round_mode, clamp_ste) if the fused kernels can take the integer range from device tensors"""
+        if not config.FUSED_PATHS or not bit_width.is_cuda or bit_width.numel() != 1 or zero_point.requires_grad:
+            return None
+        round_mode = getattr(self.float_to_int_impl, 'bvq_round_mode', None)
+        clamp_ste = getattr(self.tensor_clamp_impl, 'bvq_clamp_ste', None)
+        if round_mode is None or clamp_ste is None:
+            return None
+        p = _fused.plan(x, scale, zero_point)
+        if p is None or p.zp_pc:
+            return None
+        return p, round_mode, clamp_ste
 
 
 class DecoupledIntQuant(torch.nn.Module):

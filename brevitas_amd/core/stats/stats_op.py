@@ -466,3 +466,86 @@ class MeanLearnedSigmaStd(TolerantLoad, torch.nn.Module):
         if legacy in state_dict:
             state_dict[prefix + 'sigma'] = state_dict.pop(legacy)
         super()._load_from_state_dict(state_dict, prefix, *hook_args)
+
+
+class KLMinimizerThreshold(torch.nn.Module):
+    """Clipping threshold that minimises the KL divergence between the histogram of x and its quantized version
+    (drop-in for B/core/stats/stats_op.py:280-350, itself after MXNet's calibration).
+
+    The two passes over x -- the abs-max and the `num_bins` histogram over [-absmax, absmax] -- are one streaming
+    read each on the device (bvq_stats, bvq_histc; the histogram's range is read from device memory).  The search
+    over the ~num_bins/2 candidate thresholds works on the 1001 counters on the host, like the reference's python
+    loop (an offline calibration statistic: it synchronises, as the reference's `.int()` / indexing do)."""
+    bvq_is_stat = True
+
+    def __init__(self, signed, bit_width_impl, num_bins=1000 + 1, smoothing_eps=0.0001):
+        super().__init__()
+        self.num_bins = num_bins
+        self.smoothing_eps = smoothing_eps
+        self.signed = signed
+        self.bit_width_impl = bit_width_impl
+        self.absmax_impl = AbsMax()
+
+    @staticmethod
+    def smooth_normalize_distribution(p: Tensor, eps: float):
+        """counts -> Categorical(logits = smoothed counts), None if every bin is empty (stats_op.py:295-305; the
+        reference adds its correction term to every bin and hands the counts over as LOGITS: kept as it is)"""
+        is_zeros = (p == 0).float()
+        n_zeros = is_zeros.sum()
+        n_nonzeros = torch.numel(p) - n_zeros
+        if not n_nonzeros:
+            return None
+        eps1 = eps * n_zeros / n_nonzeros
+        hist = p.float()
+        hist = hist + (eps * is_zeros + (-eps1) * n_nonzeros)
+        return torch.distributions.categorical.Categorical(logits=hist)
+
+    def _histogram(self, x: Tensor, absmax: Tensor) -> Tensor:
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and self.num_bins <= 8192:
+            return nat.histc(x.detach().reshape(-1), absmax.detach(), self.num_bins).cpu()
+        a = float(absmax)
+        return torch.histc(x.detach().float().cpu(), bins=self.num_bins, min=-a, max=a).int()
+
+    def forward(self, x: Tensor) -> Tensor:
+        from brevitas_amd.function.ops import max_int
+        absmax = self.absmax_impl(x)
+        bit_width = self.bit_width_impl()
+        bw = getattr(bit_width, 'bvq_host_value', None)
+        nq = int(max_int(self.signed, False, torch.tensor(float(bw)) if bw is not None else bit_width.detach().cpu()))
+        half, qhalf = self.num_bins // 2, nq // 2
+        hist = self._histogram(x, absmax)                      # int32 [num_bins] on the host
+        a = float(absmax)
+        hist_edges = torch.linspace(-a, a, self.num_bins + 1)
+        thresholds = torch.zeros(half + 1 - qhalf)
+        divergence = torch.zeros_like(thresholds)
+        total = hist.sum()
+        csum = torch.cumsum(hist, 0)
+        for i in range(qhalf, half + 1):
+            start, stop = half - i, half + i + 1
+            thresholds[i - qhalf] = hist_edges[stop]
+            sliced = hist[start:stop]
+            p = sliced.clone()
+            p[0] += csum[start - 1] if start > 0 else 0         # outliers fold into the edge bins
+            p[-1] += total - csum[stop - 1]
+            nonzero = (sliced != 0).float()
+            merged = torch.numel(p) // nq                       # histogram bins per quantized bin
+            body = sliced[:nq * merged].reshape(nq, merged).sum(dim=1).float()
+            body[-1] += sliced[nq * merged:].sum()
+            # every non-empty histogram bin of a quantized bin gets that bin's mean count; the reference's slice
+            # of the LAST quantized bin stops one element short of the end (stop = -1): kept
+            q = torch.zeros(p.shape, dtype=torch.float32)
+            norm = nonzero[:nq * merged].reshape(nq, merged).sum(dim=1)
+            last_lo = (nq - 1) * merged
+            norm[-1] = nonzero[last_lo:-1].sum()
+            fill = torch.where(norm != 0, body / torch.where(norm != 0, norm, torch.ones_like(norm)), torch.zeros_like(body))
+            q[:last_lo] = fill[:-1].repeat_interleave(merged)
+            q[last_lo:-1] = fill[-1]
+            q[sliced == 0] = 0.
+            pd = self.smooth_normalize_distribution(p, self.smoothing_eps)
+            qd = self.smooth_normalize_distribution(q, self.smoothing_eps)
+            if qd is None:
+                divergence[i - qhalf] = float('inf')
+            else:
+                divergence[i - qhalf] = torch.distributions.kl.kl_divergence(pd, qd)
+        return thresholds[torch.argmin(divergence)].to(x.device)
+

@@ -21,7 +21,9 @@ struct QuantArgs {
   void* codes;      // fwd only, nullable; element type codes_dtype
   const void* g;    // bwd only
   float* ds_part;   // bwd only, per-unit partial of dscale
-  float* dzp_part;  // bwd only, per-unit partial of dzp
+  float* dzp_part;  // bwd only, per-unit partial of dzp (kBwdDsBounds: of d(qmin))
+  float* dq_part;   // bwd only, kBwdDsBounds: per-unit partial of d(qmax)
+  const float* bounds;  // nullable: [qmin, qmax] as float32 ON THE DEVICE (a learned bit width) instead of qmin/qmax
   const void* tie_stat;          // bwd only: abs-max statistic (dtype of x) whose ties are recorded
   unsigned long long* tie_info;  // bwd only (bvq_ties.h)
   unsigned long long* pos_part;  // bwd only: per-unit first position attaining tie_stat (instead of tie_info)
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
   float s, z;
   load_scale_zp<CT>(a, u.channel, s, z);
   // the reference clamps against min_int/max_int converted to the tensor dtype (max_val.type_as(x))
-  const float qmin = rnd<CT>(a.qmin), qmax = rnd<CT>(a.qmax);
+  const float qmin = rnd<CT>(a.bounds ? a.bounds[0] : a.qmin), qmax = rnd<CT>(a.bounds ? a.bounds[1] : a.qmax);
   // wave-uniform choices: fused pre-activation, zero zero-point (16-bit compute types: saves two
   // re-roundings per element), and (bf16) the reciprocal fast path
   const bool zp0 = sizeof(CT) == 2 && zp_is_pos_zero(z);
@@ -646,13 +648,15 @@ __global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant
 //   dx     = (pass ? g*scale : 0) / scale
 //   dscale = sum g*(q - zp)  -  sum dt * ((x/scale)/scale)        (torch: -grad * ((a/b)/b))
 //   dzp    = sum dt  -  sum g*scale
-// MODE: 0 = dx only, 1 = + dscale, 2 = + dscale and dzp, 3 = + dscale and abs-max tie search.
-enum { kBwdDx = 0, kBwdDs = 1, kBwdDsDzp = 2, kBwdDsTies = 3 };
+// MODE: 0 = dx only, 1 = + dscale, 2 = + dscale and dzp, 3 = + dscale and abs-max tie search,
+// 4 = + dscale and the gradients of the clamp bounds (a learned bit width with a plain TensorClamp: the two
+//     torch.where of tensor_clamp send the gradient of a replaced value to the bound that replaced it).
+enum { kBwdDx = 0, kBwdDs = 1, kBwdDsDzp = 2, kBwdDsTies = 3, kBwdDsBounds = 4 };
 
 template <typename CT, int RM, int MODE, bool ZP0, typename Div>
 __device__ __forceinline__ float bwd_elem(float xf, float gf, const Div& div, float s, float z, float qmin,
                                           float qmax, bool clamp_ste, int mode, float& ds_acc,
-                                          float& dzp_acc) {
+                                          float& dzp_acc, float& dq_acc) {
   const float t1 = rnd<CT>(div(xf));
   const float t2 = ZP0 ? t1 + 0.f : rnd<CT>(t1 + z);
   const float t3 = do_round<CT, RM>(t2, mode);
@@ -672,13 +676,17 @@ __device__ __forceinline__ float bwd_elem(float xf, float gf, const Div& div, fl
     ds_acc += term2;
   }
   if constexpr (MODE == kBwdDsDzp) dzp_acc += dt - gs;
+  if constexpr (MODE == kBwdDsBounds) {
+    dzp_acc += lo ? gs : 0.f;  // d(qmin)
+    dq_acc += hi ? gs : 0.f;   // d(qmax)
+  }
   return dxv;
 }
 
 // bwd_elem on a pair of elements; the sums are kept as pairs too (added up once per unit)
 template <typename CT, int RM, int MODE, bool ZP0, bool SAME16, typename Div, typename S>
 __device__ __forceinline__ f2 bwd_elem2(f2 xf, f2 gf, const Div& div, S s, S z, float qmin, float qmax,
-                                        bool clamp_ste, int mode, f2& ds_acc, f2& dzp_acc) {
+                                        bool clamp_ste, int mode, f2& ds_acc, f2& dzp_acc, f2& dq_acc) {
   const f2 t1 = rnd2<CT>(div(xf));
   const f2 t2 = ZP0 ? t1 + 0.f : rnd2<CT>(t1 + z);
   const f2 t3 = do_round2<CT, RM>(t2, mode);
@@ -705,6 +713,10 @@ __device__ __forceinline__ f2 bwd_elem2(f2 xf, f2 gf, const Div& div, S s, S z, 
     ds_acc += term2;
   }
   if constexpr (MODE == kBwdDsDzp) dzp_acc += dt - gs;
+  if constexpr (MODE == kBwdDsBounds) {
+    dzp_acc += lo ? gs : splat2(0.f);  // d(qmin)
+    dq_acc += hi ? gs : splat2(0.f);   // d(qmax)
+  }
   return dxv;
 }
 
@@ -725,10 +737,10 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
   if constexpr (MODE == kBwdDsTies)
     stat_bits = abs_bits<XT>(reinterpret_cast<const XT*>(a.tie_stat)[u.channel]);
 
-  float ds_acc = 0.f, dzp_acc = 0.f;
+  float ds_acc = 0.f, dzp_acc = 0.f, dq_acc = 0.f;
   uint32_t umax = 0;  // kBwdDsTies: largest |x| key this lane has seen in the unit's full chunks
   unsigned long long tie_first = ~0ull;
-  f2 ds_acc2 = splat2(0.f), dzp_acc2 = splat2(0.f);  // pairwise path; folded into the scalars at the end
+  f2 ds_acc2 = splat2(0.f), dzp_acc2 = splat2(0.f), dq_acc2 = splat2(0.f);  // pairwise path; folded into the scalars at the end
   // the work on one chunk (VEC elements of x and g -> VEC elements of dx, sums and the chunk's largest |x| key)
   auto chunk = [&](const vec_t<XT, VEC>& xv, const vec_t<CT, VEC>& gv, int64_t off) {
     vec_t<XT, VEC> dv;
@@ -738,7 +750,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
         const f2 xraw = widen2<XT>(xv.v[k], xv.v[k + 1]);
         constexpr bool kSame16 = sizeof(CT) == 2 && sizeof(XT) == 2;  // then XT is CT (dispatch pairs)
         f2 d = bwd_elem2<CT, RM, MODE, ZP0, kSame16>(PRE ? relu2(xraw) : xraw, widen2<CT>(gv.v[k], gv.v[k + 1]),
-                                            div, s, z, qmin, qmax, clamp_ste, mode, ds_acc2, dzp_acc2);
+                                            div, s, z, qmin, qmax, clamp_ste, mode, ds_acc2, dzp_acc2, dq_acc2);
         if constexpr (PRE) d = xraw > splat2(0.f) ? d : splat2(0.f);  // torch.relu backward: grad * (x > 0)
         pack2<XT>(d, dv.v[k], dv.v[k + 1]);
       }
@@ -747,7 +759,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
       for (int k = 0; k < VEC; ++k) {
         const float xraw = to_f<XT>(xv.v[k]);
         float d = bwd_elem<CT, RM, MODE, ZP0>(PRE ? relu_f(xraw) : xraw, to_f<CT>(gv.v[k]), div, s, z,
-                                              qmin, qmax, clamp_ste, mode, ds_acc, dzp_acc);
+                                              qmin, qmax, clamp_ste, mode, ds_acc, dzp_acc, dq_acc);
         if constexpr (PRE) d = xraw > 0.f ? d : 0.f;  // torch.relu backward: grad * (x > 0)
         dv.v[k] = from_f<XT>(d);
       }
@@ -877,7 +889,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
     const int64_t i = (int64_t)tr * u.row_stride + in_row;
     const float xraw = to_f<XT>(xp[i]);
     float d = bwd_elem<CT, RM, MODE, ZP0>(PRE ? relu_f(xraw) : xraw, to_f<CT>(gp[i]), div, s, z, qmin, qmax,
-                                          clamp_ste, mode, ds_acc, dzp_acc);
+                                          clamp_ste, mode, ds_acc, dzp_acc, dq_acc);
     if constexpr (PRE) d = xraw > 0.f ? d : 0.f;
     dxp[i] = from_f<XT>(d);
     if constexpr (MODE == kBwdDsTies) {
@@ -902,9 +914,14 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
     dzp_acc += dzp_acc2.x + dzp_acc2.y;
     ds_acc = wave_sum(ds_acc);
     if (lane == 0) a.ds_part[u.id] = ds_acc;
-    if constexpr (MODE == kBwdDsDzp) {
+    if constexpr (MODE == kBwdDsDzp || MODE == kBwdDsBounds) {
       dzp_acc = wave_sum(dzp_acc);
       if (lane == 0) a.dzp_part[u.id] = dzp_acc;
+    }
+    if constexpr (MODE == kBwdDsBounds) {
+      dq_acc += dq_acc2.x + dq_acc2.y;
+      dq_acc = wave_sum(dq_acc);
+      if (lane == 0) a.dq_part[u.id] = dq_acc;
     }
   }
 }
@@ -916,7 +933,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96), amdgpu_
   if (!u.valid) return;
   float s, z;
   load_scale_zp<CT>(a, u.channel, s, z);
-  const float qmin = rnd<CT>(a.qmin), qmax = rnd<CT>(a.qmax);
+  const float qmin = rnd<CT>(a.bounds ? a.bounds[0] : a.qmin), qmax = rnd<CT>(a.bounds ? a.bounds[1] : a.qmax);
   const bool zp0 = sizeof(CT) == 2 && zp_is_pos_zero(z);
 #define BVQ_BWD_UNIT(ZP0, PRE, DIV) bwd_unit<XT, CT, VEC, RM, MODE, NT, ZP0, PRE, NTX>(a, u, DIV, s, z, qmin, qmax)
 #define BVQ_BWD_PRE(ZP0, DIV)      \
@@ -1018,13 +1035,13 @@ __device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const Cols
           f2 d;
           if constexpr (FAST && elem<T>::id == BVQ_F16)
             d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivF16V{ln.s2[k / 2], r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2],
-                                                       qmin, qmax, clamp_ste, mode, ds2[k / 2], dz_unused);
+                                                       qmin, qmax, clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
           else if constexpr (FAST)
             d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivBf16V{r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax,
-                                                       clamp_ste, mode, ds2[k / 2], dz_unused);
+                                                       clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
           else
             d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivExactV{ln.s2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin,
-                                                       qmax, clamp_ste, mode, ds2[k / 2], dz_unused);
+                                                       qmax, clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
           if (a.pre_relu) d = xraw > splat2(0.f) ? d : splat2(0.f);
           pack2<T>(d, dv.v[k], dv.v[k + 1]);
         }
@@ -1368,6 +1385,9 @@ static void launch_bwd(const QuantArgs& a, int vec, int mode, bool nt, hipStream
     case kBwdDsDzp:
       launch_bwd_mode<XT, CT, kBwdDsDzp>(a, vec, nt, st);
       break;
+    case kBwdDsBounds:
+      launch_bwd_mode<XT, CT, kBwdDsBounds>(a, vec, nt, st);
+      break;
     default:
       launch_bwd_mode<XT, CT, kBwdDsTies>(a, vec, nt, st);
       break;
@@ -1396,8 +1416,8 @@ static void launch_bwd(const QuantArgs& a, int vec, int mode, bool nt, hipStream
 using namespace bvq;
 
 #if BVQ_PART == 0 || BVQ_PART == 1
-extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const void* scale,
-                                 const void* zp, void* y, void* codes, bvq_stream_t stream) {
+static int fakequant_fwd_impl(const bvq_quant_desc* d, const void* x, const void* scale, const void* zp, void* y,
+                             void* codes, const float* bounds, bvq_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
   const int64_t n = d->outer * d->channels * d->inner;
@@ -1406,7 +1426,7 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
     set_error("bvq_fakequant_fwd: null pointer");
     return BVQ_ERR_INVALID;
   }
-  if (y && !codes) {
+  if (y && !codes && !bounds) {
     const ColsPlan cp = cols_quant_plan(d, x, y, nullptr);
     if (cp.ok) {
       ColsQuantArgs ca = {};
@@ -1438,6 +1458,7 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
   a.zp = zp;
   a.y = y;
   a.codes = codes;
+  a.bounds = bounds;
   fill_args(a, d);
   hipStream_t st = (hipStream_t)stream;
   const bool nt = n * (int64_t)(dtype_size(d->x_dtype) + dtype_size(d->ct_dtype)) >= nt_threshold_bytes();
@@ -1445,6 +1466,20 @@ extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const v
   BVQ_DISPATCH_PAIR(d, BVQ_CALL);
 #undef BVQ_CALL
   return check_launch("bvq_fakequant_fwd");
+}
+
+extern "C" int bvq_fakequant_fwd(const bvq_quant_desc* d, const void* x, const void* scale,
+                                 const void* zp, void* y, void* codes, bvq_stream_t stream) {
+  return fakequant_fwd_impl(d, x, scale, zp, y, codes, nullptr, stream);
+}
+
+extern "C" int bvq_fakequant_fwd_bounds(const bvq_quant_desc* d, const void* x, const void* scale, const void* zp,
+                                        const float* bounds, void* y, bvq_stream_t stream) {
+  if (!bounds) {
+    set_error("bvq_fakequant_fwd_bounds: null bounds");
+    return BVQ_ERR_INVALID;
+  }
+  return fakequant_fwd_impl(d, x, scale, zp, y, nullptr, bounds, stream);
 }
 
 
@@ -1591,7 +1626,7 @@ extern "C" int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* d) {
   rows_of(d, outer, row_len, channels);
   const int64_t units = bwd_units(d);
   const int64_t mid = channel_sums_mid_bytes(units / channels + 1, channels) + 16;
-  int64_t bytes = 2 * units * (int64_t)sizeof(float) + mid + 256;
+  int64_t bytes = 3 * units * (int64_t)sizeof(float) + mid + 256;  // (a third partial array: bvq_fakequant_bwd_bounds)
   const ColsPlan cp = cols_quant_plan(d, nullptr, nullptr, nullptr);
   if (cp.ok && (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(float) + 256 > bytes)
     bytes = (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(float) + 256;
@@ -1601,7 +1636,8 @@ extern "C" int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* d) {
 static int fakequant_bwd_impl(const bvq_quant_desc* d, const void* g, const void* x, const void* scale,
                              const void* zp, void* dx, float* dscale, float* dzp, const void* tie_stat,
                              int64_t* tie_info, void* workspace, int64_t workspace_bytes, bvq_stream_t stream,
-                             const LearnedScaleEpilogue* epilogue) {
+                             const LearnedScaleEpilogue* epilogue, const float* bounds = nullptr,
+                             float* dbounds = nullptr) {
   int rc = validate(d);
   if (rc) return rc;
   const int64_t n = d->outer * d->channels * d->inner;
@@ -1633,7 +1669,11 @@ static int fakequant_bwd_impl(const bvq_quant_desc* d, const void* g, const void
     set_error("bvq_fakequant_bwd: null pointer");
     return BVQ_ERR_INVALID;
   }
-  if (!dzp) {
+  if (dbounds && (dzp || tie_stat || !dscale)) {
+    set_error("bvq_fakequant_bwd: the bound gradients ride on the dscale variant (dscale set, dzp / tie_stat null)");
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  if (!dzp && !bounds) {
     const ColsPlan cp = cols_quant_plan(d, x, g, dx);
     if (cp.ok) {
       const int64_t need = dscale ? (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(float) : 0;
@@ -1677,7 +1717,7 @@ static int fakequant_bwd_impl(const bvq_quant_desc* d, const void* g, const void
   int64_t mid_off = 0;
   if (need_sums) {
     // float partials (8-byte aligned end), then the doubles of a split reduction
-    mid_off = ((2 * a.t.units * (int64_t)sizeof(float) + 7) / 8) * 8;
+    mid_off = (((dbounds ? 3 : 2) * a.t.units * (int64_t)sizeof(float) + 7) / 8) * 8;
     const int64_t need = mid_off + channel_sums_mid_bytes(a.t.nob * a.t.ppr, channels);
     if (!workspace || workspace_bytes < need) {
       set_error("bvq_fakequant_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes,
@@ -1686,16 +1726,18 @@ static int fakequant_bwd_impl(const bvq_quant_desc* d, const void* g, const void
     }
     a.ds_part = reinterpret_cast<float*>(workspace);
     a.dzp_part = a.ds_part + a.t.units;
+    a.dq_part = a.dzp_part + a.t.units;
   }
   a.x = x;
   a.g = g;
   a.scale = scale;
   a.zp = zp;
   a.y = dx;
+  a.bounds = bounds;
   a.tie_stat = tie_stat;
   a.tie_info = reinterpret_cast<unsigned long long*>(tie_info);
   fill_args(a, d);
-  const int mode = tie_stat ? kBwdDsTies : (dzp ? kBwdDsDzp : (dscale ? kBwdDs : kBwdDx));
+  const int mode = dbounds ? kBwdDsBounds : (tie_stat ? kBwdDsTies : (dzp ? kBwdDsDzp : (dscale ? kBwdDs : kBwdDx)));
   const bool nt =
       n * (int64_t)(2 * dtype_size(d->x_dtype) + dtype_size(d->ct_dtype)) >= nt_threshold_bytes();
 #define BVQ_CALL(XT, CT) launch_bwd<XT, CT>(a, vec, mode, nt, st)
@@ -1704,8 +1746,14 @@ static int fakequant_bwd_impl(const bvq_quant_desc* d, const void* g, const void
   rc = check_launch("bvq_fakequant_bwd");
   if (rc) return rc;
   if (need_sums) {
-    launch_channel_sums(dscale ? a.ds_part : nullptr, dzp ? a.dzp_part : nullptr, dscale, dzp, a.t.nob, channels,
-                        a.t.ppr, reinterpret_cast<char*>(workspace) + mid_off, st, epilogue);
+    // dbounds: [d(qmin) per channel | d(qmax) per channel] (the bounds themselves are scalars: the caller adds the
+    // channels up)
+    launch_channel_sums(dscale ? a.ds_part : nullptr, (dzp || dbounds) ? a.dzp_part : nullptr, dscale,
+                        dbounds ? dbounds : dzp, a.t.nob, channels, a.t.ppr,
+                        reinterpret_cast<char*>(workspace) + mid_off, st, epilogue);
+    if (dbounds)
+      launch_channel_sums(a.dq_part, nullptr, dbounds + channels, nullptr, a.t.nob, channels, a.t.ppr,
+                          reinterpret_cast<char*>(workspace) + mid_off, st, nullptr);
     rc = check_launch("bvq_fakequant_bwd/channel_sum");
   }
   return rc;
@@ -1717,6 +1765,17 @@ extern "C" int bvq_fakequant_bwd(const bvq_quant_desc* d, const void* g, const v
                                  int64_t workspace_bytes, bvq_stream_t stream) {
   return fakequant_bwd_impl(d, g, x, scale, zp, dx, dscale, dzp, tie_stat, tie_info, workspace, workspace_bytes,
                             stream, nullptr);
+}
+
+extern "C" int bvq_fakequant_bwd_bounds(const bvq_quant_desc* d, const void* g, const void* x, const void* scale,
+                                        const void* zp, const float* bounds, void* dx, float* dscale, float* dbounds,
+                                        void* workspace, int64_t workspace_bytes, bvq_stream_t stream) {
+  if (!bounds || !dscale) {
+    set_error("bvq_fakequant_bwd_bounds: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  return fakequant_bwd_impl(d, g, x, scale, zp, dx, dscale, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                            stream, nullptr, bounds, dbounds);
 }
 
 extern "C" int bvq_fakequant_bwd_learned(const bvq_quant_desc* d, const void* g, const void* x, const void* scale,

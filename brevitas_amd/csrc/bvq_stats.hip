@@ -1117,6 +1117,75 @@ extern "C" int bvq_scale_from_stat(const float* stat32, int64_t channels, int st
   return check_launch("bvq_scale_from_stat");
 }
 
+// ---- histogram over [-absmax, absmax] (KLMinimizerThreshold, B/core/stats/stats_op.py:311-312) ------------------
+// torch.histc(x, bins, min=-absmax, max=absmax): equal-width bins, values outside the range ignored, the value `max`
+// itself counted in the last bin; bin = (int)((v - min) * bins / (max - min)) in float32, the device kernel's formula
+// (ATen/native/cuda/SummaryOps.cu, getBin).  One streaming read; per-workgroup bins in LDS, flushed with one
+// atomic add per non-empty bin.  absmax is read from the device (dtype of x): no host sync.
+constexpr int kHistMaxBins = 8192;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void histc_kernel(const T* __restrict__ x, int64_t n, const void* absmax,
+                                                       int32_t bins, int* __restrict__ out) {
+  __shared__ int sh[kHistMaxBins];
+  for (int i = threadIdx.x; i < bins; i += kBlock) sh[i] = 0;
+  __syncthreads();
+  const float hi = to_f<T>(*reinterpret_cast<const T*>(absmax)), lo = -hi;
+  const float width = hi - lo;
+  constexpr int VEC = elem<T>::vec;
+  const int64_t nvec = n / VEC;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  auto count = [&](float v) {
+    if (v >= lo && v <= hi) {
+      int b = (int)((v - lo) * (float)bins / width);
+      if (b == bins) b -= 1;
+      if (b >= 0 && b < bins) atomicAdd(&sh[b], 1);  // (width == 0: NaN bin index, nothing counted by the guard)
+    }
+  };
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+    const vec_t<T, VEC> xv = load_vec<T, VEC>(x + i * VEC);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) count(to_f<T>(xv.v[k]));
+  }
+  const int64_t t = nvec * VEC + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t < n) count(to_f<T>(x[t]));
+  __syncthreads();
+  for (int i = threadIdx.x; i < bins; i += kBlock)
+    if (sh[i]) atomicAdd(&out[i], sh[i]);
+}
+
+__global__ void histc_zero_kernel(int* p, int32_t n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
+extern "C" int bvq_histc(int dtype, const void* x, int64_t n, const void* absmax, int bins, int32_t* counts,
+                         bvq_stream_t stream) {
+  if (bad_dtype(dtype) || n < 0 || bins < 1 || bins > kHistMaxBins || !counts || !absmax || (n > 0 && !x)) {
+    set_error("bvq_histc: bad argument (1 <= bins <= %d)", kHistMaxBins);
+    return BVQ_ERR_INVALID;
+  }
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) {
+    set_error("bvq_histc: x must be 16-byte aligned");
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  histc_zero_kernel<<<dim3((unsigned)((bins + 255) / 256)), dim3(256), 0, st>>>(counts, bins);
+  if (n > 0) {
+    const int64_t per_block = (int64_t)kBlock * 16 * (16 / dtype_size(dtype));
+    int64_t blocks = (n + per_block - 1) / per_block;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks), block(kBlock);
+    if (dtype == BVQ_F32)
+      histc_kernel<float><<<grid, block, 0, st>>>(reinterpret_cast<const float*>(x), n, absmax, bins, counts);
+    else if (dtype == BVQ_BF16)
+      histc_kernel<bf16_t><<<grid, block, 0, st>>>(reinterpret_cast<const bf16_t*>(x), n, absmax, bins, counts);
+    else
+      histc_kernel<f16_t><<<grid, block, 0, st>>>(reinterpret_cast<const f16_t*>(x), n, absmax, bins, counts);
+  }
+  return check_launch("bvq_histc");
+}
+
 // learned scale, forward:  scale = |clamp_min_ste(value, min_val)| / int_threshold  in ONE launch
 // (ParameterScaling.forward, B/core/scaling/standalone.py:143-146, then the division of
 // RescalingIntQuant.forward, B/core/quant/int.py:160): clamp and |.| are exact, the quotient is rounded to

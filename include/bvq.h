@@ -216,6 +216,14 @@ int bvq_shard_pack(const float* dscale, const int64_t* tie_info, int64_t channel
 int bvq_shard_unpack(const double* gathered, int world, int64_t channels, int rank, int per_channel,
                      float* dscale_total, int64_t* tie_info, int64_t* total_ties, bvq_stream_t stream);
 
+/* ---- histogram (KLMinimizerThreshold, B/core/stats/stats_op.py:280-350) -----------------------------------
+ * counts[b] = number of elements of x in bin b of torch.histc(x, bins, min=-absmax, max=absmax) -- equal-width
+ * bins, values outside the range ignored, bin = (int)((v + absmax) * bins / (2 absmax)) in float32, the value
+ * +absmax in the last bin.  absmax: ONE element on the device in x's dtype (the AbsMax statistic: no host
+ * sync); counts: int32 [bins], overwritten; 1 <= bins <= 8192.  One streaming read of x. */
+int bvq_histc(int dtype, const void* x, int64_t n, const void* absmax, int bins, int32_t* counts,
+              bvq_stream_t stream);
+
 /* ---- moment statistics ---------------------------------------------------------------------------
  * sums is float32 [3 * channels]: sums[c] = SUM d, sums[channels + c] = SUM d^2 over the `outer` and `inner`
  * axes with d = |x| - p[c], and sums[2 * channels + c] = p[c], the channel's pivot (|x| of its first element,
@@ -385,6 +393,20 @@ int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* desc);
 int bvq_fakequant_bwd(const bvq_quant_desc* desc, const void* g, const void* x, const void* scale,
                       const void* zp, void* dx, float* dscale, float* dzp, const void* tie_stat,
                       int64_t* tie_info, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
+
+/* Learned bit widths (BitWidthParameter, B/core/bit_width/parameter.py:23-100): the integer range is then a pair of
+ * 0-dim tensors in the autograd graph (min_int / max_int of the bit-width tensor, B/function/ops.py:132-191), not
+ * host numbers.  `bounds` = [qmin, qmax] as float32 ON THE DEVICE replaces desc->qmin / qmax (no host sync):
+ * bvq_fakequant_fwd_bounds is bvq_fakequant_fwd reading them; bvq_fakequant_bwd_bounds is bvq_fakequant_bwd(dscale)
+ * that also returns, when dbounds is non-null (a plain TensorClamp: tensor_clamp's two torch.where send the gradient
+ * of a replaced value to the bound that replaced it), dbounds[0 .. n) = per-channel sums of the gradient reaching
+ * qmin and dbounds[n .. 2n) of that reaching qmax (n = channels for per-channel scales, else 1; the caller adds the
+ * channels up).  With a straight-through clamp pass dbounds = null.  Workspace: bvq_fakequant_bwd_workspace_bytes. */
+int bvq_fakequant_fwd_bounds(const bvq_quant_desc* desc, const void* x, const void* scale, const void* zp,
+                             const float* bounds, void* y, bvq_stream_t stream);
+int bvq_fakequant_bwd_bounds(const bvq_quant_desc* desc, const void* g, const void* x, const void* scale,
+                             const void* zp, const float* bounds, void* dx, float* dscale, float* dbounds,
+                             void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
 
 /* Learned scales (ParameterScaling, and ParameterFromRuntimeStatsScaling once its collection phase is over:
  * the steady state of the default Int8ActPerTensorFloat; B/core/scaling/standalone.py:75-152, 155-298), float

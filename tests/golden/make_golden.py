@@ -750,7 +750,7 @@ def gen_fixed_point():
 def gen_learned_bw():
     from brevitas.core.bit_width import BitWidthParameter, MsbClampBitWidth, RemoveBitwidthParameter
     st = Store('learned_bw')
-    for dn in ('f32', 'bf16'):
+    for dn in ('f32', 'bf16', 'f16'):
         # weight: per-channel abs-max scale, straight-through clamp -> d(bit width) through the scale only
         w = torch.nn.Parameter((torch.randn(6, 4, 3, 3) * 0.3).to(DT[dn]))
         q = RescalingIntQuant(
@@ -814,10 +814,31 @@ def gen_moments():
     st.save()
 
 
+# ------------------------------------------------------------------------------------------------
+# L. KLMinimizerThreshold (B/core/stats/stats_op.py:280-350): threshold search over the histogram of x
+# ------------------------------------------------------------------------------------------------
+def gen_kl():
+    from brevitas.core.stats.stats_op import KLMinimizerThreshold
+    st = Store('kl_threshold')
+    for tag, signed, bits, make in (
+            ('gauss_s8', True, 8, lambda: torch.randn(40000) * 1.5),
+            ('gauss_s4', True, 4, lambda: torch.randn(40000) * 0.7),
+            ('heavy_tail_s8', True, 8, lambda: torch.randn(40000) * torch.exp(torch.randn(40000))),
+            ('relu_u8', False, 8, lambda: torch.relu(torch.randn(40000)) * 2.0),
+            ('sparse_s6', True, 6, lambda: torch.randn(40000) * (torch.rand(40000) < 0.1).float())):
+        x = make()
+        m = KLMinimizerThreshold(signed, BitWidthConst(bits))
+        out = m(x)
+        a = float(x.abs().max())
+        hist = torch.histc(x, bins=1001, min=-a, max=a).int()
+        st.case({'tag': tag, 'signed': signed, 'bits': bits}, x=x, out=out, hist=hist)
+    st.save()
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     only = sys.argv[1:]
-    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point', 'learned_bw', 'moments'}:
+    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point', 'learned_bw', 'moments', 'kl'}:
         # the first four files were generated in ONE run, in this order, from a single seed
         torch.manual_seed(123456)
         gen_ste()
@@ -845,3 +866,6 @@ if __name__ == '__main__':
     if not only or 'moments' in only:
         torch.manual_seed(123463)
         gen_moments()
+    if not only or 'kl' in only:
+        torch.manual_seed(123464)
+        gen_kl()

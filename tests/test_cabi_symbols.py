@@ -78,3 +78,52 @@ def test_build_script_runs_without_a_loadable_library():
     assert r.stdout.strip().endswith('libbvq.so')
     r = subprocess.run([sys.executable, '-c', 'import brevitas_amd'], cwd=root, env=env, capture_output=True, text=True)
     assert r.returncode != 0 and 'There is no fallback backend' in r.stderr  # the product import still fails loudly
+
+
+def _header_prototypes():
+    """name -> (return type, [parameter types]) of every function declared in include/bvq.h, types as written"""
+    text = open(os.path.join(ROOT, 'include', 'bvq.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r'^\s*((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\*?)\s*(bvq_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;', text,
+                         flags=re.M | re.S):
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+        ps = [] if params.strip() in ('', 'void') else [re.sub(r'\s+', ' ', p.strip()) for p in params.split(',')]
+        # drop the parameter name: everything up to the last identifier
+        types = [re.sub(r'\s*[A-Za-z_][A-Za-z0-9_]*$', '', p).strip() if not p.endswith('*') else p for p in ps]
+        protos[name] = (re.sub(r'\s+', ' ', ret.strip()), types)
+    return protos
+
+
+def _ctype_of(c_type, nat):
+    t = c_type.replace('const ', '').strip()
+    if t in ('bvq_quant_desc*', 'bvq_quant_desc *'):
+        return ctypes.POINTER(nat.QuantDesc)
+    if t in ('bvq_variant_desc*', 'bvq_variant_desc *'):
+        return ctypes.POINTER(nat.VariantDesc)
+    if t.endswith('*') or t == 'bvq_stream_t':
+        return ctypes.c_void_p
+    return {'int': ctypes.c_int, 'int32_t': ctypes.c_int, 'int64_t': ctypes.c_int64, 'double': ctypes.c_double,
+            'float': ctypes.c_float}[t]
+
+
+def test_python_binding_signatures_match_the_header():
+    """every argtypes / restype list of brevitas_amd._native mirrors the prototype in include/bvq.h: same arity,
+    same kind of every parameter (pointer, 32- or 64-bit integer, double) -- a drift here corrupts arguments silently"""
+    from brevitas_amd import _native as nat
+    protos = _header_prototypes()
+    checked = 0
+    for name in nat.EXPORTS:
+        fn = getattr(nat.lib, name)
+        if fn.argtypes is None:      # bvq_abi_version / bvq_last_error take nothing
+            assert protos[name][1] == [], name
+            continue
+        ret, params = protos[name]
+        want = [_ctype_of(p, nat) for p in params]
+        assert len(fn.argtypes) == len(want), (name, len(fn.argtypes), params)
+        for i, (a, b) in enumerate(zip(fn.argtypes, want)):
+            assert a is b or (a in (ctypes.c_int, ctypes.c_int32) and b in (ctypes.c_int, ctypes.c_int32)), (name, i, a, b)
+        assert fn.restype is {'int': ctypes.c_int, 'int64_t': ctypes.c_int64}[ret] or \
+            (fn.restype in (ctypes.c_int, ctypes.c_int32) and ret == 'int'), (name, fn.restype, ret)
+        checked += 1
+    assert checked >= 40

@@ -32,7 +32,7 @@ def on_cpu(monkeypatch):
 from test_gpu_modules import (test_act_param_from_stats, test_act_parameter_scale, test_act_runtime_stats,  # noqa: E402,F401
                               test_const_scale_doctest, test_int_codes_emission,
                               test_int_quant_doctest_and_tensor_bit_width, test_int_quant_module_golden,
-                              test_param_from_stats_state_dict_keys, test_weight_per_channel)
+                              test_param_from_stats_state_dict_keys, test_qcdq_operand_package, test_weight_per_channel)
 # the 12 STE ops with autograd, the plain ops' doctests, the statistics with autograd
 from test_gpu_ste_stats_modules import (test_ops_ste_functions_with_autograd, test_plain_ops_doctests,  # noqa: E402,F401
                                         test_stats_modules_with_autograd,

@@ -1,8 +1,9 @@
 """Learned bit widths (B/core/bit_width/parameter.py, const.py:43-66) against the
-reference's resolved graphs (tests/golden/learned_bw.npz).  The bit width is a tensor in the autograd
-graph, so the quantizer takes the op-by-op route on the HIP-backed elementwise ops: y, scale, bit width
-and dx bit-exact (f32; bf16 within the documented 0-dim-scalar rounding of the device), the reduced
-gradients (bit-width offset, learned scale) within a few ulps of the summed magnitude."""
+reference's resolved graphs (tests/golden/learned_bw.npz; float32, bfloat16, float16).  The bit width is a
+tensor in the autograd graph: the fused quantizer kernels read the integer range from device memory and
+return the range's own gradient (bvq_fakequant_fwd_bounds / bvq_fakequant_bwd_bounds), so the quantizer is
+still one forward and one backward pass: y, scale, bit width and dx bit-exact, the reduced gradients
+(bit-width offset, learned scale) within the rounding of a reduced sum.  `generic`: the op-by-op route."""
 import numpy as np
 import pytest
 import torch
@@ -48,34 +49,40 @@ def _quant(graph, weight=None, bits=4):
         IntScaling(signed=True, narrow_range=False), ZeroZeroPoint(), BitWidthParameter(bits)).to(DEV)
 
 
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'generic'])
 @pytest.mark.parametrize('c', [k for k in CASES if k['graph'] == 'weight'], ids=lambda c: c['dtype'])
-def test_weight_learned_bit_width(c):
+def test_weight_learned_bit_width(c, fused, monkeypatch):
+    import brevitas_amd.config as config
+    monkeypatch.setattr(config, 'FUSED_PATHS', fused)
     w = torch.nn.Parameter(c.torch('x', DEV))
     q = _quant('weight', w)
     y, scale, zp, bw = q(w)
     assert bw.requires_grad
     assert_bits(bw, c, 'bit_width')
     assert_bits(scale, c, 'scale')
-    if c['dtype'] == 'f32':
+    if c['dtype'] == 'f32' or fused:
         assert_bits(y, c, 'y')
     y.backward(c.torch('g', DEV))
-    if c['dtype'] == 'f32':
+    if c['dtype'] == 'f32' or fused:
         _dx_check(w.grad, c, 6)
     _close(q.msb_clamp_bit_width_impl.bit_width_offset.grad, c, 'doffset', 2e-3 if c['dtype'] == 'f32' else 6e-2)
 
 
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'generic'])
 @pytest.mark.parametrize('c', [k for k in CASES if k['graph'] == 'act'],
                          ids=lambda c: '%d-%s' % (c['bits'], c['dtype']))
-def test_act_learned_bit_width(c):
+def test_act_learned_bit_width(c, fused, monkeypatch):
+    import brevitas_amd.config as config
+    monkeypatch.setattr(config, 'FUSED_PATHS', fused)
     q = _quant('act', bits=c['bits'])
     x = c.torch('x', DEV).requires_grad_(True)
     y, scale, zp, bw = q(x)
     assert_bits(bw, c, 'bit_width')
     assert_bits(scale, c, 'scale')
-    if c['dtype'] == 'f32':
+    if c['dtype'] == 'f32' or fused:
         assert_bits(y, c, 'y')
     y.backward(c.torch('g', DEV))
-    if c['dtype'] == 'f32':
+    if c['dtype'] == 'f32' or fused:
         assert_bits(x.grad, c, 'dx')
     tol = 2e-3 if c['dtype'] == 'f32' else 6e-2
     _close(q.msb_clamp_bit_width_impl.bit_width_offset.grad, c, 'doffset', tol)

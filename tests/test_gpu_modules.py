@@ -348,6 +348,32 @@ def test_int_codes_emission(c):
         assert np.array_equal(codes2.cpu().numpy()[fin], codes.cpu().numpy()[fin])
 
 
+@pytest.mark.parametrize('c', [k for k in INT_QUANT if k['x_dtype'] == 'f32'],
+                         ids=G.ids([k for k in INT_QUANT if k['x_dtype'] == 'f32'], ['layout', 'round', 'clamp', 'bit_width']))
+def test_qcdq_operand_package(c):
+    """codes + scale + zero-point + axis in the layout the reference's QCDQ export handlers assemble
+    (B/export/common/handler/qcdq.py:92-150): de-quantizing them reproduces the reference's fake-quantized y"""
+    from brevitas_amd.core.function_wrapper import (CeilSte, DPURoundSte, FloorSte, RoundSte, RoundToZeroSte,
+                                                    TensorClamp, TensorClampSte)
+    m = mods()
+    rimpl = {'round': RoundSte, 'floor': FloorSte, 'ceil': CeilSte, 'rtz': RoundToZeroSte, 'dpu': DPURoundSte}
+    iq = m['IntQuant'](narrow_range=c['narrow'], signed=c['signed'], float_to_int_impl=rimpl[c['round']](),
+                       tensor_clamp_impl=TensorClampSte() if c['clamp'] == 'ste' else TensorClamp()).to(DEV)
+    bw = m['BitWidthConst'](c['bit_width']).to(DEV)()
+    x, scale, zp = c.torch('x', DEV), c.torch('scale', DEV), c.torch('zp', DEV)
+    ops = iq.to_qcdq_operands(scale, zp, bw, x)
+    assert ops.int_codes.dtype == (torch.int8 if c['signed'] else torch.uint8) == ops.zero_point.dtype
+    if scale.numel() == 1:
+        assert ops.axis is None and ops.scale.dim() == 0
+    else:
+        assert ops.axis == [i for i, s in enumerate(scale.shape) if s != 1][0]
+        assert ops.scale.shape == (scale.numel(),) and ops.zero_point.shape == ops.scale.shape
+    want = c.f32('y').reshape(-1)
+    got = ops.dequantize().float().cpu().numpy().reshape(-1)
+    fin = np.isfinite(want) & np.isfinite(c.f32('x').reshape(-1))
+    assert np.allclose(got[fin], want[fin], rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
 @pytest.mark.parametrize('signed', [True, False])
 def test_int_codes_emission_channels_last(dtype, signed):

@@ -28,7 +28,7 @@ def _dx_check(dx, c, max_deposits):
     bad = np.nonzero((got != want) & ~(np.isnan(gf) & np.isnan(wf)))[0]
     assert bad.size <= max_deposits, (bad.size, max_deposits)
     scale = max(1.0, float(np.abs(wf).max()))
-    tol = {'f32': 2e-4, 'bf16': 2.0 ** -5}[c['dtypes']['dx']] * 64 * scale
+    tol = {'f32': 2e-4, 'bf16': 2.0 ** -5, 'f16': 2.0 ** -8}[c['dtypes']['dx']] * 64 * scale
     assert np.all(np.abs(gf[bad] - wf[bad]) <= tol), (gf[bad], wf[bad])
 
 
