@@ -39,7 +39,7 @@ EXPORTS = (
     'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd',
     'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd_stats_workspace_bytes', 'bvq_fakequant_bwd_stats', 'bvq_fakequant_bwd',
     'bvq_learned_scale', 'bvq_fakequant_bwd_learned', 'bvq_variant_fwd', 'bvq_variant_bwd_workspace_bytes', 'bvq_variant_bwd',
-    'bvq_fakequant_fwd_bounds', 'bvq_fakequant_bwd_bounds', 'bvq_histc')
+    'bvq_fakequant_fwd_bounds', 'bvq_fakequant_bwd_bounds', 'bvq_histc', 'bvq_absmax_scale_running')
 
 
 class QuantDesc(ctypes.Structure):
@@ -97,6 +97,7 @@ def _load(path=None, strict=True):
         'bvq_fakequant_bwd_stats_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
         'bvq_fakequant_bwd_stats': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, i32, dbl, i32, vp, i64, vp]),
         'bvq_absmax_scale': (i32, [i32, i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
+        'bvq_absmax_scale_running': (i32, [i32, i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, i32, vp, dbl, i32, vp, i64, vp]),
         'bvq_running_stats_update': (i32, [i32, vp, i32, vp, i64, dbl, i32, vp]),
         'bvq_scale_from_stat': (i32, [vp, i64, i32, vp, dbl, i32, dbl, i32, vp, vp]),
         'bvq_shard_pack': (i32, [vp, vp, i64, i32, i32, vp, vp]),
@@ -368,8 +369,10 @@ def stats_fakequant_fwd(desc, x, min_val, int_threshold, scale_dtype):
     return stat, scale, y
 
 
-def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype, pre_op=PRE_NONE):
-    """abs-max statistic and the scale derived from it, one call: -> (stat [channels], scale [channels])"""
+def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype, pre_op=PRE_NONE, running=None,
+                 momentum=0.0, first_batch=False):
+    """abs-max statistic and the scale derived from it, one call: -> (stat [channels], scale [channels]);
+    running (contiguous [channels] buffer): also folded with the statistic in the same finishing launch"""
     dev = require_device(x)
     assert x.is_contiguous() and x.numel() == outer * channels * inner
     dt = dtype_code(x.dtype)
@@ -380,9 +383,16 @@ def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype,
     with _DeviceGuard(dev):
         if _timer is not None:
             _timer.before('bvq_stats')
-        check(lib.bvq_absmax_scale(pre_op, dt, ptr(x), outer, channels, inner, ptr(stat), float(min_val or 0.0),
-                                   int(bool(min_val)), float(int_threshold), dtype_code(scale_dtype), ptr(scale),
-                                   ptr(ws), ws.numel(), stream_ptr(dev)), 'bvq_absmax_scale')
+        if running is not None:
+            check(lib.bvq_absmax_scale_running(pre_op, dt, ptr(x), outer, channels, inner, ptr(stat),
+                                               float(min_val or 0.0), int(bool(min_val)), float(int_threshold),
+                                               dtype_code(scale_dtype), ptr(scale), dtype_code(running.dtype),
+                                               ptr(running), float(momentum), int(first_batch), ptr(ws), ws.numel(),
+                                               stream_ptr(dev)), 'bvq_absmax_scale_running')
+        else:
+            check(lib.bvq_absmax_scale(pre_op, dt, ptr(x), outer, channels, inner, ptr(stat), float(min_val or 0.0),
+                                       int(bool(min_val)), float(int_threshold), dtype_code(scale_dtype), ptr(scale),
+                                       ptr(ws), ws.numel(), stream_ptr(dev)), 'bvq_absmax_scale')
         if _timer is not None:
             _timer.after('bvq_stats')
     return stat, scale

@@ -343,9 +343,11 @@ def _as_dtype_value(v: float, dtype: torch.dtype) -> float:
     return r
 
 
-def stats_scale(flat: Tensor, int_threshold: Tensor, sp, group, pre_op):
+def stats_scale(flat: Tensor, int_threshold: Tensor, sp, group, pre_op, running=None):
     """AbsMax statistic of the [outer, channels, inner] tensor `flat` and the scale derived from it:
-    -> (stat [channels] in x's dtype, scale shaped sp.scaling_shape).  group: the tensor is one batch shard."""
+    -> (stat [channels] in x's dtype, scale shaped sp.scaling_shape).  group: the tensor is one batch shard.
+    running: (buffer, momentum, first_batch) of a _RuntimeStats to fold the statistic into in the same launch
+    (unsharded route only; the caller checks `running_folded`)."""
     if group is None:
         # statistic -> clamp_min -> / int_threshold in the reduction's own finishing launch.
         # torch's promotion: a dimensioned threshold keeps its dtype (the 0-dim float32
@@ -355,8 +357,13 @@ def stats_scale(flat: Tensor, int_threshold: Tensor, sp, group, pre_op):
         else:
             scale_dtype = torch.promote_types(flat.dtype, int_threshold.dtype)
             thr_div = sp.int_threshold
-        stat, scale = nat.absmax_scale(flat, sp.outer, sp.channels, sp.inner, sp.min_val, thr_div, scale_dtype,
-                                       pre_op)
+        if running is not None:
+            buf, momentum, first = running
+            stat, scale = nat.absmax_scale(flat, sp.outer, sp.channels, sp.inner, sp.min_val, thr_div, scale_dtype,
+                                           pre_op, running=buf, momentum=momentum, first_batch=first)
+        else:
+            stat, scale = nat.absmax_scale(flat, sp.outer, sp.channels, sp.inner, sp.min_val, thr_div, scale_dtype,
+                                           pre_op)
         return stat, scale.view(sp.scaling_shape)
     # batch-sharded tensor: the statistic of the whole batch is the max over the shards
     from brevitas_amd.distributed import sync_stat_max
@@ -382,7 +389,8 @@ class StatsFakeQuantFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, group=None, pre_op=nat.PRE_NONE):
+    def forward(ctx, x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, group=None, pre_op=nat.PRE_NONE,
+                runtime=None):
         ctx.set_materialize_grads(False)  # an unused `scale` output must not cost a zero-fill + add
         ctx.pre_op = pre_op
         xc, back = _memory_order(x, sp.channels, sp.nhwc)
@@ -407,7 +415,15 @@ class StatsFakeQuantFn(Function):
             stat, scale, y = fused
             scale = scale.view(sp.scaling_shape)
         else:
-            stat, scale = stats_scale(flat, int_threshold, sp, group, pre_op)
+            # _RuntimeStats' running average rides on the statistic's finishing launch when its buffer is a plain
+            # [channels] device tensor (the module is told through `bvq_running_folded`)
+            running = None
+            if runtime is not None and group is None:
+                buf = runtime.running_stats
+                if buf.is_cuda and buf.is_contiguous() and buf.numel() == sp.channels and buf.dtype in _FLOATS:
+                    running = (buf, runtime.momentum, runtime.first_batch)
+                    runtime.bvq_running_folded = True
+            stat, scale = stats_scale(flat, int_threshold, sp, group, pre_op, running)
             p = Plan(sp.outer, sp.channels, sp.inner, sp.channels > 1, False, torch.result_type(x, scale), sp.nhwc)
             if not (p.ct == x.dtype or p.ct == torch.float32):
                 raise nat.BvqError('StatsFakeQuantFn: unsupported operand layout (caller must pre-check)')
@@ -431,7 +447,7 @@ class StatsFakeQuantFn(Function):
         ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
         if gy is None:  # only `scale` was used downstream
             if gscale is None:
-                return None, None, None, None, None, None, None, None, None
+                return None, None, None, None, None, None, None, None, None, None
             gy = torch.zeros(xc.shape, dtype=ct, device=xc.device)
         else:
             gy = _like_memory_order(gy.to(ct), ctx.back)
@@ -443,7 +459,7 @@ class StatsFakeQuantFn(Function):
             dx = nat.fakequant_bwd_stats(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), stat,
                                          scale.dtype, thr_div, scale.dtype)
             if dx is not None:
-                return _restore(dx, ctx.back), None, None, None, None, None, None, None, None
+                return _restore(dx, ctx.back), None, None, None, None, None, None, None, None, None
         # one pass: dx, the scale-gradient sums and the positions attaining the statistic
         dx, ds, _, ties = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), True,
                                             False, tie_stat=stat)
@@ -455,7 +471,7 @@ class StatsFakeQuantFn(Function):
             thr_div = _as_dtype_value(sp.int_threshold, scale.dtype) if dimensioned else sp.int_threshold
             nat.stat_tie_apply_dscale(xc.reshape(-1), stat, ds, scale.dtype, thr_div, quot_dtype, ties,
                                       dx.reshape(-1), sp.outer, sp.channels, sp.inner, pre_op=ctx.pre_op)
-            return _restore(dx, ctx.back), None, None, None, None, None, None, None, None
+            return _restore(dx, ctx.back), None, None, None, None, None, None, None, None, None
         if ctx.group is not None:
             # sum the shards' partial sums, and agree on which shard deposits the statistic's gradient
             from brevitas_amd.distributed import sync_backward
@@ -470,4 +486,4 @@ class StatsFakeQuantFn(Function):
         dstat = (ds / int_threshold).to(stat.dtype).reshape(-1).contiguous()
         nat.stat_tie_apply(nat.MATCH_ABS, xc.reshape(-1), stat, dstat, ties, dx.reshape(-1), sp.outer,
                            sp.channels, sp.inner, mode_add=True, total_ties=total_ties, pre_op=ctx.pre_op)
-        return _restore(dx, ctx.back), None, None, None, None, None, None, None, None
+        return _restore(dx, ctx.back), None, None, None, None, None, None, None, None, None

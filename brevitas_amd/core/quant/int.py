@@ -243,11 +243,16 @@ class RescalingIntQuant(torch.nn.Module):
             int_threshold = self.int_scaling_impl(bit_width)
             # a batch-sharded activation (brevitas_amd.distributed.shard_over_batch); weights are replicated
             group = getattr(self, 'bvq_shard_group', None) if runtime is not None else None
+            if runtime is not None:
+                runtime.bvq_running_folded = False
             y, scale, stat = _fused.StatsFakeQuantFn.apply(
                 x, int_threshold, sp, tmpl['qmin'], tmpl['qmax'], tmpl['round_mode'], tmpl['clamp_ste'], group,
-                pre_op)
+                pre_op, runtime)
             if runtime is not None:
-                runtime.update_running_stats(stat)
+                if runtime.bvq_running_folded:   # updated by the statistic's own finishing launch
+                    runtime.first_batch = False
+                else:
+                    runtime.update_running_stats(stat)
             zero_point = self.zero_point_impl(x, scale, bit_width)
             return y, scale, zero_point, bit_width
         learned = self._learned_scale_args(x, bit_width)

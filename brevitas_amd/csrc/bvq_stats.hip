@@ -378,7 +378,24 @@ struct ScaleEpilogue {
   int32_t use_min;
   float min_val;
   float int_threshold;
+  // optionally, in the same launch: _RuntimeStats' running average of the statistic (B/core/stats/stats_wrapper.py:61-66)
+  void* running;    // null: none
+  int32_t run_dtype, first_batch;
+  float momentum, one_minus_m;
 };
+
+// running *= out (first batch)  |  running *= (1 - momentum); running += momentum * out -- every torch op rounds to
+// its result dtype: running's for the in-place ops, out's for momentum * out
+__device__ __forceinline__ float running_update(float r, float o, int run_dtype, int stat_dtype, float one_minus_m,
+                                                float m, int first) {
+  auto round_to = [](float v, int dt) {
+    return dt == BVQ_F32 ? v : (dt == BVQ_BF16 ? rnd<bf16_t>(v) : rnd<f16_t>(v));
+  };
+  if (first) return round_to(r * o, run_dtype);
+  r = round_to(r * one_minus_m, run_dtype);
+  const float u = round_to(o * m, stat_dtype);
+  return round_to(r + u, run_dtype);
+}
 
 // Combines the per-unit partials of one channel.  grid = (channels, splits): with splits == 1 the
 // workgroup of channel c reduces all of them and writes the statistic (and the scale epilogue); a
@@ -466,6 +483,12 @@ __global__ __launch_bounds__(kBlock) void stat_finish_kernel(const uint32_t* __r
         const float thr = (ep.use_min && v < ep.min_val) ? ep.min_val : v;  // NaN passes, like torch.clamp_min
         store_stat(ep.scale_out, ep.scale_dtype, c, thr / ep.int_threshold);
       }
+      if (ep.running) {
+        const float r = load_scalar_as_f(ep.running, ep.run_dtype, c);
+        // (v as the statistic tensor holds it: out_dtype is x's dtype on this route)
+        store_stat(ep.running, ep.run_dtype, c,
+                   running_update(r, v, ep.run_dtype, out_dtype, ep.one_minus_m, ep.momentum, ep.first_batch));
+      }
     } else {
       const float qn = __builtin_nanf("");
       store_stat(out, out_dtype, c, shnan[0] ? qn : shx[0]);
@@ -540,16 +563,7 @@ __global__ void running_stats_kernel(void* running, int run_dtype, const void* s
   if (i >= n) return;
   float r = load_scalar_as_f(running, run_dtype, i);
   const float o = load_scalar_as_f(stat, stat_dtype, i);
-  auto round_to = [](float v, int dt) {
-    return dt == BVQ_F32 ? v : (dt == BVQ_BF16 ? rnd<bf16_t>(v) : rnd<f16_t>(v));
-  };
-  if (first) {
-    r = round_to(r * o, run_dtype);
-  } else {
-    r = round_to(r * one_minus_m, run_dtype);
-    const float u = round_to(o * m, stat_dtype);
-    r = round_to(r + u, run_dtype);
-  }
+  r = running_update(r, o, run_dtype, stat_dtype, one_minus_m, m, first);
   store_stat(running, run_dtype, i, r);
 }
 
@@ -965,12 +979,37 @@ extern "C" int bvq_absmax_scale(int pre_op, int dtype, const void* x, int64_t ou
     set_error("bvq_absmax_scale: bad argument");
     return BVQ_ERR_INVALID;
   }
-  ScaleEpilogue ep;
+  ScaleEpilogue ep = {};
   ep.scale_out = scale_out;
   ep.scale_dtype = scale_dtype;
   ep.use_min = use_min;
   ep.min_val = round_host((float)min_val, dtype);  // python scalar -> the statistic's dtype
   ep.int_threshold = (float)int_threshold;
+  return stats_impl(BVQ_STAT_ABSMAX, pre_op, dtype, x, outer, channels, inner, dtype, stat_out, ep, workspace,
+                    workspace_bytes, stream);
+}
+
+extern "C" int bvq_absmax_scale_running(int pre_op, int dtype, const void* x, int64_t outer, int64_t channels,
+                                        int64_t inner, void* stat_out, double min_val, int use_min,
+                                        double int_threshold, int scale_dtype, void* scale_out, int run_dtype,
+                                        void* running, double momentum, int first_batch, void* workspace,
+                                        int64_t workspace_bytes, bvq_stream_t stream) {
+  if (bad_dtype(scale_dtype) || bad_dtype(run_dtype) || !scale_out || !running || !(int_threshold == int_threshold)) {
+    set_error("bvq_absmax_scale_running: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  ScaleEpilogue ep = {};
+  ep.scale_out = scale_out;
+  ep.scale_dtype = scale_dtype;
+  ep.use_min = use_min;
+  ep.min_val = round_host((float)min_val, dtype);
+  ep.int_threshold = (float)int_threshold;
+  ep.running = running;
+  ep.run_dtype = run_dtype;
+  ep.first_batch = first_batch;
+  // torch turns the python scalars (1 - momentum) and momentum into float32 for these dtypes (bvq_running_stats_update)
+  ep.one_minus_m = (float)(1.0 - momentum);
+  ep.momentum = (float)momentum;
   return stats_impl(BVQ_STAT_ABSMAX, pre_op, dtype, x, outer, channels, inner, dtype, stat_out, ep, workspace,
                     workspace_bytes, stream);
 }
@@ -1106,7 +1145,7 @@ extern "C" int bvq_scale_from_stat(const float* stat32, int64_t channels, int st
     set_error("bvq_scale_from_stat: bad argument");
     return BVQ_ERR_INVALID;
   }
-  ScaleEpilogue ep;
+  ScaleEpilogue ep = {};
   ep.scale_out = scale_out;
   ep.scale_dtype = scale_dtype;
   ep.use_min = use_min;
@@ -1205,7 +1244,7 @@ extern "C" int bvq_learned_scale(int value_dtype, const void* value, int64_t n, 
     set_error("bvq_learned_scale: bad argument");
     return BVQ_ERR_INVALID;
   }
-  ScaleEpilogue ep;
+  ScaleEpilogue ep = {};
   ep.scale_out = scale_out;
   ep.scale_dtype = scale_dtype;
   ep.use_min = use_min;

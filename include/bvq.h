@@ -191,6 +191,14 @@ int bvq_stats_pre(int kind, int pre_op, int dtype, const void* x, int64_t outer,
 int bvq_absmax_scale(int pre_op, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
                      void* stat_out, double min_val, int use_min, double int_threshold, int scale_dtype,
                      void* scale_out, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
+/* bvq_absmax_scale whose finishing launch ALSO folds the statistic into _RuntimeStats' running average
+ * (B/core/stats/stats_wrapper.py:61-66): first_batch: running *= stat; else running *= (1 - momentum);
+ * running += momentum * stat -- the rounding points of bvq_running_stats_update, one launch fewer per step.
+ * running: [channels] in run_dtype, updated in place. */
+int bvq_absmax_scale_running(int pre_op, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+                             void* stat_out, double min_val, int use_min, double int_threshold, int scale_dtype,
+                             void* scale_out, int run_dtype, void* running, double momentum, int first_batch,
+                             void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
 
 /* Running average kept by _RuntimeStats (B/core/stats/stats_wrapper.py:61-66), one launch:
  *   first_batch: running *= stat ; otherwise running *= (1 - momentum); running += momentum * stat
