@@ -138,6 +138,69 @@ __device__ __forceinline__ void store_vec(T* p, const vec_t<T, N>& v) {
   }
 }
 
+// ---- buffer addressing (raw buffer loads / stores with hardware bounds checking) -------------------------
+// A unit's memory seen through a 128-bit buffer descriptor (base = the unit's first element, num_records = its
+// byte extent): a lane that has nothing to load passes kBufSkip as its byte offset, the load returns zeros
+// WITHOUT a memory access and the store is dropped.  That keeps a software-pipelined loop free of branches
+// and execution-mask regions -- with a predicated global_load inside, the compiler's wait-count insertion
+// falls back to vmcnt(0) at every join and the pipeline drains on every step (tools/hot_loop_isa.py shows
+// the waits).  Offsets are 32 bits: the host keeps every unit's extent below 2^31 bytes (cap_unit_extent).
+constexpr uint32_t kBufSkip = 0x80000000u;
+constexpr int64_t kMaxUnitBytes = 0x7fffffff;
+#ifdef __HIPCC__
+typedef __amdgpu_buffer_rsrc_t buf_t;
+template <typename T>
+__device__ __forceinline__ buf_t make_buf(const T* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, bytes, 0x00020000);
+}
+template <typename T, int N, bool NT = false>
+__device__ __forceinline__ vec_t<T, N> buf_load(buf_t b, uint32_t byte_off) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  constexpr int kAux = NT ? 2 : 0;  // the `nt` bit
+  if constexpr (sizeof(T) * N == 16) {
+    return __builtin_bit_cast(vec_t<T, N>, __builtin_amdgcn_raw_buffer_load_b128(b, byte_off, 0, kAux));
+  } else if constexpr (sizeof(T) * N == 32) {
+    struct pair_t {
+      u32x4 a, b;
+    } r;
+    r.a = __builtin_amdgcn_raw_buffer_load_b128(b, byte_off, 0, kAux);
+    r.b = __builtin_amdgcn_raw_buffer_load_b128(b, byte_off + 16u, 0, kAux);
+    return __builtin_bit_cast(vec_t<T, N>, r);
+  } else if constexpr (sizeof(T) * N == 8) {
+    return __builtin_bit_cast(vec_t<T, N>, __builtin_amdgcn_raw_buffer_load_b64(b, byte_off, 0, kAux));
+  } else if constexpr (sizeof(T) * N == 4) {
+    return __builtin_bit_cast(vec_t<T, N>, __builtin_amdgcn_raw_buffer_load_b32(b, byte_off, 0, kAux));
+  } else {
+    static_assert(sizeof(T) * N == 2, "buf_load: 2, 4, 8, 16 or 32 bytes");
+    return __builtin_bit_cast(vec_t<T, N>, __builtin_amdgcn_raw_buffer_load_b16(b, byte_off, 0, kAux));
+  }
+}
+template <typename T, int N, bool NT = false>
+__device__ __forceinline__ void buf_store(buf_t b, uint32_t byte_off, const vec_t<T, N>& v) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  constexpr int kAux = NT ? 2 : 0;
+  if constexpr (sizeof(T) * N == 16) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b, byte_off, 0, kAux);
+  } else if constexpr (sizeof(T) * N == 32) {
+    struct pair_t {
+      u32x4 a, b;
+    };
+    const pair_t r = __builtin_bit_cast(pair_t, v);
+    __builtin_amdgcn_raw_buffer_store_b128(r.a, b, byte_off, 0, kAux);
+    __builtin_amdgcn_raw_buffer_store_b128(r.b, b, byte_off + 16u, 0, kAux);
+  } else if constexpr (sizeof(T) * N == 8) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), b, byte_off, 0, kAux);
+  } else if constexpr (sizeof(T) * N == 4) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), b, byte_off, 0, kAux);
+  } else {
+    static_assert(sizeof(T) * N == 2, "buf_store: 2, 4, 8, 16 or 32 bytes");
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), b, byte_off, 0, kAux);
+  }
+}
+#endif
+
 // bytes a call must stream before its kernels switch to the non-temporal policy
 int64_t nt_threshold_bytes();
 // host-side float -> dtype -> float rounding (python scalars that torch converts to the tensor dtype)
@@ -224,6 +287,10 @@ int pick_vec(int max_vec, int64_t rows, int64_t row_len, const void* const* ptrs
 
 Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, int64_t unit_cap = 0,
                    bool few_rows = false);
+// fewer rows per unit until every unit's byte extent (first to last element, elsize bytes each) stays below
+// kMaxUnitBytes: the kernels that address a unit through a buffer descriptor use 32-bit offsets.  False if a
+// single piece is already larger (no tensor that fits the device gets there).
+bool cap_unit_extent(Tiling& t, int elsize);
 
 // ---- column-mapped decomposition -------------------------------------------------------------------
 // For layouts whose channel axis is last or nearly last (x[outer, channels, inner] with a short `inner`:
@@ -331,6 +398,10 @@ struct ChunkCursor {
   }
   __device__ __forceinline__ int64_t pos(int64_t row_len, int vec) const {
     return (int64_t)row * row_len + (int64_t)chunk * vec;
+  }
+  // the offset in 32 bits, for units addressed through a buffer descriptor (extent < 2^31 bytes)
+  __device__ __forceinline__ uint32_t offset32(uint32_t row_stride, int vec) const {
+    return (uint32_t)row * row_stride + (uint32_t)chunk * (uint32_t)vec;
   }
 };
 

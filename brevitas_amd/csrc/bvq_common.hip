@@ -203,6 +203,18 @@ Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, in
   return t;
 }
 
+bool cap_unit_extent(Tiling& t, int elsize) {
+  const int64_t stride_b = (int64_t)t.channels * t.row_len * elsize;
+  const int64_t piece_b = t.piece_len * elsize;
+  if (piece_b > kMaxUnitBytes) return false;
+  if (t.rpu > 1 && (t.rpu - 1) * stride_b + piece_b > kMaxUnitBytes) {
+    t.rpu = (int32_t)(1 + (kMaxUnitBytes - piece_b) / stride_b);
+    t.nob = (t.outer + t.rpu - 1) / t.rpu;
+    t.units = t.nob * t.channels * t.ppr;
+  }
+  return true;
+}
+
 }  // namespace bvq
 
 extern "C" int bvq_abi_version(void) { return BVQ_ABI_VERSION; }

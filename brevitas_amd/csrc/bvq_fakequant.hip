@@ -741,8 +741,16 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
   uint32_t umax = 0;  // kBwdDsTies: largest |x| key this lane has seen in the unit's full chunks
   unsigned long long tie_first = ~0ull;
   f2 ds_acc2 = splat2(0.f), dzp_acc2 = splat2(0.f), dq_acc2 = splat2(0.f);  // pairwise path; folded into the scalars at the end
+  // the unit through buffer descriptors (bvq_common.h): lanes past the unit's end load zeros without touching
+  // memory -- x = g = 0 adds nothing to any sum and is no tie -- and their stores are dropped, so the walk below
+  // needs no branch and no execution mask
+  const int64_t extent = (int64_t)(u.nrows - 1) * u.row_stride + u.len;  // elements, first to last of the unit
+  const buf_t bx = make_buf(xp, (uint32_t)(extent * (int64_t)sizeof(XT)));
+  const buf_t bg = make_buf(gp, (uint32_t)(extent * (int64_t)sizeof(CT)));
+  const buf_t bd = make_buf(dxp, (uint32_t)(extent * (int64_t)sizeof(XT)));
+  constexpr uint32_t kSkip = 0x60000000u;  // element offset whose byte offset is >= 2^31 for 2- and 4-byte elements
   // the work on one chunk (VEC elements of x and g -> VEC elements of dx, sums and the chunk's largest |x| key)
-  auto chunk = [&](const vec_t<XT, VEC>& xv, const vec_t<CT, VEC>& gv, int64_t off) {
+  auto chunk = [&](const vec_t<XT, VEC>& xv, const vec_t<CT, VEC>& gv, uint32_t off) {
     vec_t<XT, VEC> dv;
     if constexpr (VEC % 2 == 0) {
 #pragma unroll
@@ -785,74 +793,71 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
         }
       }
     }
-    store_vec<XT, VEC, NT>(dxp + off, dv);
+    buf_store<XT, VEC, NT>(bd, off * (uint32_t)sizeof(XT), dv);  // dropped where off is kSkip
   };
   ChunkCursor cur;
   cur.init(u, VEC, lane);
   const int64_t total = (int64_t)u.nrows * cur.cpr;
   if constexpr (elem<CT>::id == BVQ_F16) {
-    // float16: batches of two chunks per stream, loaded together, then worked on.  The guarded reciprocal's
-    // wave-wide checks (DivF16) make the pipelined form below 20 % SLOWER here (profiles/r02_backward_variants.txt).
+    // float16: batches of two chunks per stream, loaded together, then worked on.  Its arithmetic (two converts per
+    // rounding, the guarded reciprocal's wave-wide checks) is what bounds it, and the pipelined form below is
+    // 7-20 % SLOWER here (profiles/r02_backward_variants.txt).
     constexpr int kU = 2;
+    const uint32_t rs = (uint32_t)u.row_stride;
     for (int64_t done = 0; done < total; done += (int64_t)kWave * kU) {
       vec_t<XT, VEC> xv[kU];
       vec_t<CT, VEC> gv[kU];
-      int64_t off[kU];
-      bool ok[kU];
+      uint32_t off[kU];
 #pragma unroll
       for (int j = 0; j < kU; ++j) {
-        ok[j] = cur.valid();
-        off[j] = cur.offset(u.row_stride, VEC);
-        const int64_t lo = ok[j] ? off[j] : 0;  // past the end: re-read the unit's first chunk
-        xv[j] = load_vec<XT, VEC, NTX>(xp + lo);
-        gv[j] = load_vec<CT, VEC, NT>(gp + lo);
+        off[j] = cur.valid() ? cur.offset32(rs, VEC) : kSkip;
+        xv[j] = buf_load<XT, VEC, NTX>(bx, off[j] * (uint32_t)sizeof(XT));
+        gv[j] = buf_load<CT, VEC, NT>(bg, off[j] * (uint32_t)sizeof(CT));
         cur.next();
       }
 #pragma unroll
       for (int j = 0; j < kU; ++j)
-        if (ok[j]) chunk(xv[j], gv[j], off[j]);
+        if (done + (int64_t)j * kWave < total) chunk(xv[j], gv[j], off[j]);  // wave-uniform: a step no lane has is not computed
     }
   } else {
     // Software-pipelined walk: the loads of chunk i + kD are issued BEFORE chunk i is worked on, so every wave
     // keeps kD chunks of x and of g in flight while it computes (the counters of the round-1 kernel showed its
     // waves 45 % of their time in arithmetic or waiting to issue with nothing in flight:
-    // profiles/r02/pmc_backward.md).  One chunk per step, so a 56x56 row (392 chunks) costs 7 steps of
-    // arithmetic instead of 4 x 2.
-    constexpr int kD = kBwdDepth;
+    // profiles/r02/pmc_backward_r01_kernel.md).  One chunk per step, so a 56x56 row (392 chunks) costs 7 steps
+    // of arithmetic instead of 4 x 2.
+    // (a 32-byte chunk of g -- float32 arithmetic next to a 16-bit tensor -- at depth 4 would spill)
+    constexpr int kD = sizeof(CT) * VEC > 16 ? 2 : kBwdDepth;
+    // kD + 1 register sets, walked round-robin: step i works on set i % kS while chunk i + kD is loaded into set
+    // (i - 1) % kS, the one step i - 1 has just finished with.  (With kD sets the refill of a slot overlaps the
+    // work on its old contents and the compiler copies 8 registers aside per step: 2.6 of 21 issues per element.)
+    constexpr int kS = kD + 1;
     const int32_t steps = (int32_t)((total + kWave - 1) / kWave);  // chunks per lane, the last possibly partial
-    vec_t<XT, VEC> xb[kD];
-    vec_t<CT, VEC> gb[kD];
-    int64_t offb[kD];
-    bool okb[kD];
+    const uint32_t rs = (uint32_t)u.row_stride;
+    vec_t<XT, VEC> xb[kS];
+    vec_t<CT, VEC> gb[kS];
+    uint32_t offb[kS];
 #pragma unroll
     for (int j = 0; j < kD; ++j) {
-      okb[j] = cur.valid();
-      offb[j] = cur.offset(u.row_stride, VEC);
-      if (j < steps) {  // wave-uniform
-        const int64_t lo = okb[j] ? offb[j] : 0;  // past the end: re-read the unit's first chunk
-        xb[j] = load_vec<XT, VEC, NTX>(xp + lo);
-        gb[j] = load_vec<CT, VEC, NT>(gp + lo);
-      }
+      offb[j] = cur.valid() ? cur.offset32(rs, VEC) : kSkip;
+      xb[j] = buf_load<XT, VEC, NTX>(bx, offb[j] * (uint32_t)sizeof(XT));
+      gb[j] = buf_load<CT, VEC, NT>(bg, offb[j] * (uint32_t)sizeof(CT));
       cur.next();
+      // Keep the issue order.  The loop's waits are counts of the loads issued AFTER the chunk a step needs; left
+      // alone, the scheduler issues chunk 0 among the last and the first step of every trip waits for all but the
+      // newest three loads.  (Costs 17 registers, one wave per SIMD, and is still 1-5 % faster on every box:
+      // profiles/r02_backward_variants.txt.)
+      __builtin_amdgcn_sched_barrier(0);
     }
-    for (int32_t base = 0; base < steps; base += kD) {
+    for (int32_t base = 0; base < steps; base += kS) {
 #pragma unroll
-      for (int j = 0; j < kD; ++j) {
+      for (int j = 0; j < kS; ++j) {
         if (base + j >= steps) break;  // wave-uniform
-        const vec_t<XT, VEC> xv = xb[j];
-        const vec_t<CT, VEC> gv = gb[j];
-        const int64_t off = offb[j];
-        const bool ok = okb[j];
-        // refill this slot with chunk base + j + kD
-        okb[j] = cur.valid();
-        offb[j] = cur.offset(u.row_stride, VEC);
-        if (base + j + kD < steps) {
-          const int64_t lo = okb[j] ? offb[j] : 0;
-          xb[j] = load_vec<XT, VEC, NTX>(xp + lo);
-          gb[j] = load_vec<CT, VEC, NT>(gp + lo);
-        }
+        const int f = (j + kD) % kS;   // the set the previous step worked on
+        offb[f] = cur.valid() ? cur.offset32(rs, VEC) : kSkip;
+        xb[f] = buf_load<XT, VEC, NTX>(bx, offb[f] * (uint32_t)sizeof(XT));
+        gb[f] = buf_load<CT, VEC, NT>(bg, offb[f] * (uint32_t)sizeof(CT));
         cur.next();
-        if (ok) chunk(xv, gv, off);
+        chunk(xb[j], gb[j], offb[j]);
       }
     }
   }
@@ -1608,14 +1613,22 @@ extern "C" int bvq_stats_fakequant_fwd(const bvq_quant_desc* d, const void* x, d
 #endif  // forward part
 
 #if BVQ_PART == 0 || BVQ_PART == 2
+// the backward's decomposition: quantizer-style tiling with every unit addressable through 32-bit buffer offsets
+// (4 = the widest element; the same bound for every dtype so that workspace sizing and launch agree)
+static Tiling bwd_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec) {
+  Tiling t = make_tiling(outer, channels, row_len, vec, 0, true);
+  cap_unit_extent(t, 4);
+  return t;
+}
+
 static int64_t bwd_units(const bvq_quant_desc* d) {
   int64_t outer, row_len;
   int32_t channels;
   rows_of(d, outer, row_len, channels);
   // upper bound over the vector widths the launcher may pick
   const int full = 16 / dtype_size(d->x_dtype);
-  const int64_t a = make_tiling(outer, channels, row_len, full, 0, true).units;
-  const int64_t b = make_tiling(outer, channels, row_len, 1, 0, true).units;
+  const int64_t a = bwd_tiling(outer, channels, row_len, full).units;
+  const int64_t b = bwd_tiling(outer, channels, row_len, 1).units;
   return a > b ? a : b;
 }
 
@@ -1710,7 +1723,7 @@ static int fakequant_bwd_impl(const bvq_quant_desc* d, const void* g, const void
   const int full = 16 / dtype_size(d->x_dtype);
   const int vec = snap_vec(pick_vec(full, outer * channels, row_len, ptrs, els, 3, true), full);
   QuantArgs a = {};
-  a.t = make_tiling(outer, channels, row_len, vec, 0, true);
+  a.t = bwd_tiling(outer, channels, row_len, vec);
 #ifdef BVQ_CACHE_EXPERIMENT
   if (getenv("BVQ_X_BWD_REV")) a.t.reverse = atoi(getenv("BVQ_X_BWD_REV"));
 #endif
@@ -1907,7 +1920,7 @@ extern "C" int bvq_fakequant_bwd_stats(const bvq_quant_desc* d, const void* g, c
   const int full = 16 / dtype_size(d->x_dtype);
   const int vec = snap_vec(pick_vec(full, d->outer * channels, d->inner, ptrs, els, 3, true), full);
   QuantArgs a = {};
-  a.t = make_tiling(d->outer, channels, d->inner, vec, 0, true);
+  a.t = bwd_tiling(d->outer, channels, d->inner, vec);
 #ifdef BVQ_CACHE_EXPERIMENT
   if (getenv("BVQ_X_BWD_REV")) a.t.reverse = atoi(getenv("BVQ_X_BWD_REV"));
 #endif
