@@ -316,7 +316,8 @@ struct ColsPlan {
   int64_t prows;    // partial rows = nrb * rpp
   int64_t units;    // nrb * strips
 };
-ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner);
+// no_partials: the caller's kernel writes no per-unit partial rows (more, shorter units pay then)
+ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bool no_partials = false);
 
 static inline unsigned grid_for_units(int64_t units) {
   return (unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock);

@@ -98,13 +98,19 @@ int env_flag(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner) {
+ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bool no_partials) {
   static const int enabled = env_flag("BVQ_COLS", 1);
   ColsPlan p = {};
   const int el = dtype == BVQ_F32 ? 4 : 2;
   const int vec = 16 / el;
-  // short inner runs only: from 256 bytes per channel row on, the row-mapped units stream well
-  if (!enabled || channels < 2 || inner < 1 || outer < 2 || inner * el >= 256) return p;
+  // short inner runs: from 256 bytes per channel row on, the row-mapped units stream well -- unless the rows are
+  // not 16-byte multiples (14x14 maps of a 16-bit type: 392 bytes), where the row-mapped route drops to 8- or
+  // 2-byte accesses: [1024,1024,14,14] bf16 forward 3.0 -> 5.5 TB/s, abs-max 3.3 -> 5.1 on this route
+  // (profiles/r02_column_mapped.txt)
+  const int64_t row_bytes = inner * el;
+  const bool short_rows = row_bytes < 256;
+  const bool ragged_rows = row_bytes % 16 != 0 && row_bytes < 4096 && outer >= 64;
+  if (!enabled || channels < 2 || inner < 1 || outer < 2 || !(short_rows || ragged_rows)) return p;
   const int64_t L = channels * inner;
   if (L % vec != 0 || L / vec > (1 << 30)) return p;
   p.rows = outer;
@@ -117,11 +123,23 @@ ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner) {
   // rows per block: at least 16 chunks per lane, and no more than ~8192 units in all -- every unit leaves a
   // partial row of L entries behind, and those should stay a few percent of the traffic
   int64_t rb = 16 * (int64_t)p.rpp;
-  const int64_t want_blocks = 8192 / p.strips > 0 ? 8192 / p.strips : 1;
+  static const int env_units = [] {
+    const char* e = getenv("BVQ_COLS_UNITS");  // experiments only
+    const int n = e ? atoi(e) : 0;
+    return (n >= 64 && n <= (1 << 22)) ? n : 0;
+  }();
+  // (a kernel that leaves no partial rows behind -- the forward -- is faster with 8 x the units: 4.99 -> 5.70 TB/s
+  //  on [802816,512] bf16; with partial rows the extra traffic and the longer fold eat the gain)
+  const int want_units = env_units ? env_units : (no_partials ? 65536 : 8192);
+  const int64_t want_blocks = want_units / p.strips > 0 ? want_units / p.strips : 1;
   const int64_t rows_for_that = (outer + want_blocks - 1) / want_blocks;
   if (rows_for_that > rb) rb = ((rows_for_that + p.rpp - 1) / p.rpp) * p.rpp;
   // a lane's row counter within a unit fits 16 bits (the backward packs it next to a 16-bit key)
   if (rb > 65000 * (int64_t)p.rpp) rb = 65000 * (int64_t)p.rpp;
+  // a unit's byte extent fits the 32-bit offsets of a buffer descriptor (the backward addresses it that way)
+  const int64_t max_rows = kMaxUnitBytes / (L * 4);
+  if (max_rows < p.rpp) return p;
+  if (rb > max_rows) rb = (max_rows / p.rpp) * p.rpp;
   p.rb = (int32_t)rb;
   p.nrb = (outer + rb - 1) / rb;
   p.prows = p.nrb * p.rpp;

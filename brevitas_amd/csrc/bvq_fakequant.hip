@@ -1262,13 +1262,14 @@ static void fill_args(QuantArgs& a, const bvq_quant_desc* d) {
 }
 
 // column-mapped route for this call? (channel axis last or nearly last; see ColsPlan)
-static ColsPlan cols_quant_plan(const bvq_quant_desc* d, const void* p0, const void* p1, const void* p2) {
+static ColsPlan cols_quant_plan(const bvq_quant_desc* d, const void* p0, const void* p1, const void* p2,
+                                bool no_partials = false) {
   ColsPlan none = {};
   if (!(d->scale_per_channel && d->channels > 1) || d->x_dtype != d->ct_dtype || d->out_kind != BVQ_OUT_DEQUANT)
     return none;
   if ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15)
     return none;
-  return cols_plan(d->x_dtype, d->outer, d->channels, d->inner);
+  return cols_plan(d->x_dtype, d->outer, d->channels, d->inner, no_partials);
 }
 
 static void fill_cols_args(ColsQuantArgs& a, const ColsPlan& cp, const bvq_quant_desc* d) {
@@ -1432,7 +1433,7 @@ static int fakequant_fwd_impl(const bvq_quant_desc* d, const void* x, const void
     return BVQ_ERR_INVALID;
   }
   if (y && !codes && !bounds) {
-    const ColsPlan cp = cols_quant_plan(d, x, y, nullptr);
+    const ColsPlan cp = cols_quant_plan(d, x, y, nullptr, true);
     if (cp.ok) {
       ColsQuantArgs ca = {};
       fill_cols_args(ca, cp, d);
@@ -1641,8 +1642,8 @@ extern "C" int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* d) {
   const int64_t mid = channel_sums_mid_bytes(units / channels + 1, channels) + 16;
   int64_t bytes = 3 * units * (int64_t)sizeof(float) + mid + 256;  // (a third partial array: bvq_fakequant_bwd_bounds)
   const ColsPlan cp = cols_quant_plan(d, nullptr, nullptr, nullptr);
-  if (cp.ok && (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(float) + 256 > bytes)
-    bytes = (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(float) + 256;
+  if (cp.ok && (cp.prows + cols_fold_scratch_rows(cp.prows)) * cp.L * (int64_t)sizeof(float) + 256 > bytes)
+    bytes = (cp.prows + cols_fold_scratch_rows(cp.prows)) * cp.L * (int64_t)sizeof(float) + 256;
   return bytes;
 }
 
@@ -1687,9 +1688,9 @@ static int fakequant_bwd_impl(const bvq_quant_desc* d, const void* g, const void
     return BVQ_ERR_UNSUPPORTED;
   }
   if (!dzp && !bounds) {
-    const ColsPlan cp = cols_quant_plan(d, x, g, dx);
+    const ColsPlan cp = cols_quant_plan(d, x, g, dx, !dscale && !tie_stat);
     if (cp.ok) {
-      const int64_t need = dscale ? (cp.prows + cols_fold_scratch_rows()) * cp.L * (int64_t)sizeof(float) : 0;
+      const int64_t need = dscale ? (cp.prows + cols_fold_scratch_rows(cp.prows)) * cp.L * (int64_t)sizeof(float) : 0;
       if (dscale && (!workspace || workspace_bytes < need)) {
         set_error("bvq_fakequant_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
         return BVQ_ERR_WORKSPACE;
@@ -1821,7 +1822,7 @@ static bool bwd_stats_supported(const bvq_quant_desc* d, int64_t& units, int64_t
   if (!(d->scale_per_channel && d->channels > 1) || d->zp_per_channel) return false;
   const ColsPlan cp = cols_quant_plan(d, nullptr, nullptr, nullptr);
   if (cp.ok) {  // column-mapped partials: [prows][L] plus their fold [L]
-    units = (cp.prows + cols_fold_scratch_rows()) * cp.L;
+    units = (cp.prows + cols_fold_scratch_rows(cp.prows)) * cp.L;
     per_channel = d->inner;
     return true;
   }
@@ -1879,7 +1880,7 @@ extern "C" int bvq_fakequant_bwd_stats(const bvq_quant_desc* d, const void* g, c
       return BVQ_ERR_UNSUPPORTED;
     }
     if (cp.ok) {
-      const int64_t words = (cp.prows + cols_fold_scratch_rows()) * cp.L;
+      const int64_t words = (cp.prows + cols_fold_scratch_rows(cp.prows)) * cp.L;
       const int64_t pos_off_c = ((words * (int64_t)sizeof(float) + 7) / 8) * 8;
       if (workspace_bytes < pos_off_c + words * (int64_t)sizeof(unsigned long long)) {
         set_error("bvq_fakequant_bwd_stats: workspace too small");

@@ -818,8 +818,8 @@ extern "C" int64_t bvq_stats_workspace_bytes(int kind, int dtype, int64_t outer,
   int64_t partials = 2 * (units + mid) * (int64_t)sizeof(uint32_t);
   const ColsPlan cp = cols_plan(dtype, outer, channels, inner);
   // (min/max keeps two key rows per partial row)
-  if (cp.ok && (cp.prows + cols_fold_scratch_rows()) * 2 * cp.L * (int64_t)sizeof(uint32_t) > partials)
-    partials = (cp.prows + cols_fold_scratch_rows()) * 2 * cp.L * (int64_t)sizeof(uint32_t);
+  if (cp.ok && (cp.prows + cols_fold_scratch_rows(cp.prows)) * 2 * cp.L * (int64_t)sizeof(uint32_t) > partials)
+    partials = (cp.prows + cols_fold_scratch_rows(cp.prows)) * 2 * cp.L * (int64_t)sizeof(uint32_t);
   const int64_t tie = (channels > 1 ? channels : 2 + kTieCap) * (int64_t)sizeof(int64_t);
   return partials + tie + 256;
 }
@@ -859,7 +859,7 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
       (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? cols_plan(dtype, outer, channels, inner) : ColsPlan{};
   if (cp.ok) {
     const int64_t width = (kind == BVQ_STAT_MINMAX ? 2 : 1) * cp.L;  // entries per partial row
-    if (workspace_bytes < (cp.prows + cols_fold_scratch_rows()) * width * (int64_t)sizeof(uint32_t)) {
+    if (workspace_bytes < (cp.prows + cols_fold_scratch_rows(cp.prows)) * width * (int64_t)sizeof(uint32_t)) {
       set_error("bvq_stats: workspace too small");
       return BVQ_ERR_WORKSPACE;
     }

@@ -134,12 +134,24 @@ static inline void launch_channel_sums(const float* part0, const float* part1, f
   }
 }
 
-// Column-mapped partials [prows][L] -> one row [L].  Thread (j, slice) folds column j over the partial rows
-// of its slice (coalesced across j); two launches: prows -> <= kFoldSlices rows -> 1 row.
+// Column-mapped partials [prows][L] -> one row [L].  Thread (j, slice) folds column j over the kFoldRows partial
+// rows of its slice (coalesced across j, eight independent loads in flight); stages of that shrink prows by
+// kFoldRows each until at most kFoldLast rows are left for one last pass.  (Round 1 folded prows / 64 rows per
+// thread with one load in flight: at 8192 partial rows of 512 columns that pass alone took a third of the
+// abs-max's time.)
 // (templates only so that the header can be included by several translation units)
-constexpr int kFoldSlices = 64;
+constexpr int kFoldRows = 32;
+constexpr int kFoldLast = 64;
 
-static inline int64_t cols_fold_scratch_rows() { return kFoldSlices + 1; }  // rows of L entries behind the partials
+// rows of L entries the fold needs behind the partials
+static inline int64_t cols_fold_scratch_rows(int64_t prows) {
+  int64_t total = 1, r = prows;
+  while (r > kFoldLast) {
+    r = (r + kFoldRows - 1) / kFoldRows;
+    total += r;
+  }
+  return total;
+}
 
 template <int UNUSED>
 __global__ __launch_bounds__(kBlock) void cols_fold_max_kernel(const uint32_t* __restrict__ part, uint32_t* __restrict__ out,
@@ -149,9 +161,12 @@ __global__ __launch_bounds__(kBlock) void cols_fold_max_kernel(const uint32_t* _
   const int64_t o0 = (int64_t)blockIdx.y * rows_per_slice;
   const int64_t o1 = o0 + rows_per_slice < prows ? o0 + rows_per_slice : prows;
   uint32_t m = 0;
-  for (int64_t o = o0; o < o1; ++o) {
-    const uint32_t b = part[o * L + j];
-    m = b > m ? b : m;
+  for (int64_t o = o0; o < o1; o += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = part[(o + k < o1 ? o + k : o0) * L + j];  // past the end: a row already seen
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m = v[k] > m ? v[k] : m;
   }
   out[(int64_t)blockIdx.y * L + j] = m;
 }
@@ -168,44 +183,65 @@ __global__ __launch_bounds__(kBlock) void cols_fold_sum_min_kernel(const float* 
   const int64_t o1 = o0 + rows_per_slice < prows ? o0 + rows_per_slice : prows;
   double acc = 0.0;
   unsigned long long pmin = ~0ull;
-  for (int64_t o = o0; o < o1; ++o) {
-    if (ds_part) acc += (double)ds_part[o * L + j];
-    if (pos_part) {
-      const unsigned long long q = pos_part[o * L + j];
-      pmin = q < pmin ? q : pmin;
+  for (int64_t o = o0; o < o1; o += 8) {
+    float v[8];
+    unsigned long long q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t oo = o + k < o1 ? o + k : o0;
+      if (ds_part) v[k] = ds_part[oo * L + j];
+      if (pos_part) q[k] = pos_part[oo * L + j];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (ds_part) acc += o + k < o1 ? (double)v[k] : 0.0;  // rows in order: the sum does not depend on the launch shape
+      if (pos_part) pmin = q[k] < pmin ? q[k] : pmin;
     }
   }
   if (ds_part) ds_out[(int64_t)blockIdx.y * L + j] = (float)acc;
   if (pos_part) pos_out[(int64_t)blockIdx.y * L + j] = pmin;
 }
 
-// scratch: cols_fold_scratch_rows() rows of L entries; returns the final row inside it
+// scratch: cols_fold_scratch_rows(prows) rows of L entries; returns the final row inside it
 static inline uint32_t* launch_cols_fold_max(const uint32_t* part, int64_t prows, int64_t L, uint32_t* scratch,
                                              hipStream_t st) {
-  const int64_t slices = prows < kFoldSlices ? prows : kFoldSlices;
-  const int64_t rps = (prows + slices - 1) / slices;
   const unsigned gx = (unsigned)((L + kBlock - 1) / kBlock);
-  cols_fold_max_kernel<0><<<dim3(gx, (unsigned)slices), dim3(kBlock), 0, st>>>(part, scratch, prows, L, rps);
-  uint32_t* fin = scratch + (int64_t)kFoldSlices * L;
-  cols_fold_max_kernel<0><<<dim3(gx, 1), dim3(kBlock), 0, st>>>(scratch, fin, slices, L, slices);
-  return fin;
+  const uint32_t* src = part;
+  uint32_t* dst = scratch;
+  int64_t rows = prows;
+  while (rows > kFoldLast) {
+    const int64_t slices = (rows + kFoldRows - 1) / kFoldRows;
+    cols_fold_max_kernel<0><<<dim3(gx, (unsigned)slices), dim3(kBlock), 0, st>>>(src, dst, rows, L, kFoldRows);
+    src = dst;
+    dst += slices * L;
+    rows = slices;
+  }
+  cols_fold_max_kernel<0><<<dim3(gx, 1), dim3(kBlock), 0, st>>>(src, dst, rows, L, rows);
+  return dst;
 }
 
 static inline void launch_cols_fold_sum_min(const float* ds_part, const unsigned long long* pos_part, int64_t prows,
                                             int64_t L, float* ds_scratch, unsigned long long* pos_scratch,
                                             float** ds_final, unsigned long long** pos_final, hipStream_t st) {
-  const int64_t slices = prows < kFoldSlices ? prows : kFoldSlices;
-  const int64_t rps = (prows + slices - 1) / slices;
   const unsigned gx = (unsigned)((L + kBlock - 1) / kBlock);
-  cols_fold_sum_min_kernel<0><<<dim3(gx, (unsigned)slices), dim3(kBlock), 0, st>>>(ds_part, pos_part, ds_scratch,
-                                                                                   pos_scratch, prows, L, rps);
-  float* dsf = ds_part ? ds_scratch + (int64_t)kFoldSlices * L : nullptr;
-  unsigned long long* posf = pos_part ? pos_scratch + (int64_t)kFoldSlices * L : nullptr;
-  cols_fold_sum_min_kernel<0><<<dim3(gx, 1), dim3(kBlock), 0, st>>>(ds_part ? ds_scratch : nullptr,
-                                                                    pos_part ? pos_scratch : nullptr, dsf, posf, slices, L,
-                                                                    slices);
-  *ds_final = dsf;
-  if (pos_final) *pos_final = posf;
+  const float* dsrc = ds_part;
+  const unsigned long long* psrc = pos_part;
+  float* ddst = ds_part ? ds_scratch : nullptr;
+  unsigned long long* pdst = pos_part ? pos_scratch : nullptr;
+  int64_t rows = prows;
+  while (rows > kFoldLast) {
+    const int64_t slices = (rows + kFoldRows - 1) / kFoldRows;
+    cols_fold_sum_min_kernel<0><<<dim3(gx, (unsigned)slices), dim3(kBlock), 0, st>>>(dsrc, psrc, ddst, pdst, rows, L,
+                                                                                     kFoldRows);
+    dsrc = ddst;
+    psrc = pdst;
+    if (ddst) ddst += slices * L;
+    if (pdst) pdst += slices * L;
+    rows = slices;
+  }
+  cols_fold_sum_min_kernel<0><<<dim3(gx, 1), dim3(kBlock), 0, st>>>(dsrc, psrc, ddst, pdst, rows, L, rows);
+  *ds_final = ddst;
+  if (pos_final) *pos_final = pdst;
 }
 
 }  // namespace bvq

@@ -27,6 +27,12 @@ SHAPES = [((200704, 512, 1), torch.bfloat16), ((802816, 512, 1), torch.bfloat16)
 
 
 def main():
+    global SHAPES
+    # python tools/cols_bench.py 1024,1024,196,bf16 2048,2048,49,bf16 ...: other [outer, channels, inner] layouts
+    picked = [a for a in sys.argv[1:] if a.count(',') == 3]
+    if picked:
+        names = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}
+        SHAPES = [(tuple(int(v) for v in a.split(',')[:3]), names[a.split(',')[3]]) for a in picked]
     dev = 'cuda:0'
     print(os.environ.get('BREVITAS_AMD_LIB', 'libbvq.so (default build)'))
     for (outer, ch, inner), dt in SHAPES:
