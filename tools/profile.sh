@@ -3,7 +3,7 @@
 # traffic counters of the headline bench.  Summaries are written by tools/summarize_profile.py.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=${1:-$ROOT/gpurun_out/prof}
+OUT=$(realpath -m "${1:-$ROOT/gpurun_out/prof}")
 rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 200 --warmup 50 --no-cpu-baseline > "$OUT/kt_bench.json" 2> "$OUT/kt.err"
