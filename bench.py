@@ -296,6 +296,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--workload', default='act_per_channel_bf16', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--settle-steps', type=int, default=None,
+                    help='developer option: untimed steps before the warm-up so that settle + warm-up reach this many '
+                         '(default SETTLE_STEPS)')
     ap.add_argument('--no-settle', action='store_true',
                     help='developer option: do not run the untimed clock-settling steps before the warm-up')
     ap.add_argument('--timer-stride', type=int, default=8,
@@ -342,7 +345,8 @@ def main():
     job = Job(kind, dtype, device, group, rank)
     timer = KernelTimer('bvq_fakequant_bwd', 'bvq_fakequant_fwd', 'bvq_stats', 'bvq_stats_fakequant_fwd')
     nat.set_kernel_timer(timer)
-    settle = 0 if args.no_settle else max(0, SETTLE_STEPS - args.warmup)
+    settle_target = SETTLE_STEPS if args.settle_steps is None else args.settle_steps
+    settle = 0 if args.no_settle else max(0, settle_target - args.warmup)
     elapsed = timed_run(job, args.steps, args.warmup, settle, world, device, timer, args.timer_stride)
     nat.set_kernel_timer(None)
 

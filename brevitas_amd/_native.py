@@ -39,7 +39,7 @@ EXPORTS = (
     'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd',
     'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd_stats_workspace_bytes', 'bvq_fakequant_bwd_stats', 'bvq_fakequant_bwd',
     'bvq_learned_scale', 'bvq_fakequant_bwd_learned', 'bvq_variant_fwd', 'bvq_variant_bwd_workspace_bytes', 'bvq_variant_bwd',
-    'bvq_fakequant_fwd_bounds', 'bvq_fakequant_bwd_bounds', 'bvq_histc', 'bvq_absmax_scale_running')
+    'bvq_fakequant_fwd_bounds', 'bvq_fakequant_bwd_bounds', 'bvq_histc', 'bvq_absmax_scale_running', 'bvq_selftest_div_f16r')
 
 
 class QuantDesc(ctypes.Structure):
@@ -121,6 +121,7 @@ def _load(path=None, strict=True):
         'bvq_fakequant_bwd': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
         'bvq_learned_scale': (i32, [i32, vp, i64, dbl, i32, dbl, i32, vp, vp]),
         'bvq_histc': (i32, [i32, vp, i64, vp, i32, vp, vp]),
+        'bvq_selftest_div_f16r': (i32, [vp, i32, vp, i32, vp, vp]),
         'bvq_fakequant_fwd_bounds': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp]),
         'bvq_fakequant_bwd_bounds': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
         'bvq_variant_fwd': (i32, [ctypes.POINTER(VariantDesc), vp, vp, vp, vp, vp, vp, vp]),
@@ -698,6 +699,17 @@ def histc(x, absmax, bins):
         check(lib.bvq_histc(dtype_code(x.dtype), ptr(x), x.numel(), ptr(absmax.to(x.dtype).reshape(1)), int(bins),
                             ptr(counts), stream_ptr(dev)), 'bvq_histc')
     return counts
+
+
+def selftest_div_f16r(a, scales):
+    """diagnostic: the quotient the float16 kernels compute for every (scale, numerator) pair -> float32 [n_s, n_a]"""
+    dev = require_device(a, scales)
+    assert a.dtype == torch.float32 and scales.dtype == torch.float32 and a.is_contiguous() and scales.is_contiguous()
+    out = torch.empty(scales.numel(), a.numel(), dtype=torch.float32, device=dev)
+    with _DeviceGuard(dev):
+        check(lib.bvq_selftest_div_f16r(ptr(a), a.numel(), ptr(scales), scales.numel(), ptr(out), stream_ptr(dev)),
+              'bvq_selftest_div_f16r')
+    return out
 
 
 def learned_scale(value, min_val, int_threshold, scale_dtype):

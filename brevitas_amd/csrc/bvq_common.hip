@@ -38,6 +38,28 @@ int default_piece_chunks() {
   return v;
 }
 
+// the quantizer kernels (a store stream next to the loads) on long rows of 4-byte elements: 4 KiB of each stream
+// per wave -- the no-arithmetic copy of tools/yardstick.py peaks there too.  The 16-bit kernels keep 8 KiB: with the
+// scale-gradient sums they are close to the VALU limit and the per-unit work (scale, reciprocal, two wave reductions)
+// of twice as many units costs more than the shorter units give (profiles/r02_per_tensor_pieces.txt).
+static int quant_piece_chunks(int vec) {
+  static int v = [] {
+    const char* e = getenv("BVQ_QUANT_PIECE_CHUNKS");  // experiments only
+    const int n = e ? atoi(e) : 0;
+    return (n >= 1 && n <= 4096) ? n : 0;
+  }();
+  if (v) return v;
+  return vec == 4 ? 4 : default_piece_chunks();  // (vec 4 = float32 in 16-byte chunks)
+}
+static int max_units_per_channel_quant() {
+  static int v = [] {
+    const char* e = getenv("BVQ_QUANT_MAX_UNITS_PER_CHANNEL");  // experiments only
+    const int n = e ? atoi(e) : 0;
+    return (n >= 1 && n <= (1 << 24)) ? n : (1 << 20);
+  }();
+  return v;
+}
+
 int pick_vec(int max_vec, int64_t rows, int64_t row_len, const void* const* ptrs, const int* elsizes,
              int nptr, bool ragged_ok) {
   // ragged_ok: the caller's kernels walk the (< vec) elements after the last full chunk of EVERY row and
@@ -177,9 +199,10 @@ Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, in
   t.rpu = 1;
   t.reverse = 0;
   if (row_len >= piece) {
+    if (few_rows) piece = (int64_t)quant_piece_chunks(vec) * quantum;
     // long rows: cut them into default-sized pieces (a per-tensor quantizer is one very long row: ~10^5
     // units, whose partials the finish kernels combine in two stages), bounded by unit_cap per channel.
-    if (unit_cap <= 0) unit_cap = max_units_per_channel();
+    if (unit_cap <= 0) unit_cap = few_rows ? max_units_per_channel_quant() : max_units_per_channel();
     int64_t max_ppr = unit_cap / (outer > 0 ? outer : 1);
     if (max_ppr < 1) max_ppr = 1;
     if (row_len > piece * max_ppr) {

@@ -44,6 +44,17 @@ struct QuantArgs {
 #ifndef BVQ_BWD_WAVES
 #define BVQ_BWD_WAVES 4  // occupancy floor handed to the register allocator (waves per SIMD)
 #endif
+// developer switches of the float16 backward (tools/variant_bench.py): the division (0: guarded reciprocal DivF16,
+// 1: refined reciprocal product DivF16R) and the walk (0: batches of two chunks, 1: the software-pipelined walk)
+#ifndef BVQ_F16_BWD_DIV
+#define BVQ_F16_BWD_DIV 1
+#endif
+#ifndef BVQ_F16_BWD_PIPE
+#define BVQ_F16_BWD_PIPE 1
+#endif
+#ifndef BVQ_F16_COLS_DIV   // the column-mapped kernels' float16 division, same choice
+#define BVQ_F16_COLS_DIV 0
+#endif
 #ifndef BVQ_BWD_DEPTH
 #define BVQ_BWD_DEPTH 4
 #endif
@@ -155,6 +166,40 @@ struct DivF16V {
       q.x = a.x / s.x;
       q.y = a.y / s.y;
     }
+    return q;
+  }
+};
+// DivF16R : the correctly rounded float32 quotient from the correctly rounded reciprocal r = RN(1/s) (computed once
+//           per wave by an IEEE division) in four full-rate instructions per element instead of the ~11 (one of them
+//           the quarter-rate v_rcp) of a/s: q0 = a*r is within an ulp of a/s, rem = fma(-q0, s, a) is its exact
+//           remainder, fma(rem, r, q0) rounds a/s correctly (Markstein), and v_div_fixup restores what the fmas
+//           lose -- the sign of a zero numerator, an infinite numerator (rem would be NaN), NaN.  No wave-wide check,
+//           no branch.  float16 operands keep every intermediate far from float32's overflow / underflow ranges
+//           (|a/s| in [2^-38, 2^30]); equality with a/s is checked over EVERY float16 numerator x every float16
+//           scale in [2^-14, 2^14] on the GPU (tests/test_gpu_fastdiv.py) and over a sample of scales with libm's
+//           fmaf on the CPU (tests/test_fastdiv_exact.py).
+__device__ __forceinline__ float div_refined(float a, float s, float r) {
+  const float q0 = a * r;
+  const float rem = __builtin_fmaf(-q0, s, a);
+  return __builtin_amdgcn_div_fixupf(__builtin_fmaf(rem, r, q0), s, a);
+}
+struct DivF16R {
+  float s, r;
+  __device__ __forceinline__ float operator()(float a) const { return div_refined(a, s, r); }
+  __device__ __forceinline__ f2 operator()(f2 a) const {
+    f2 q = {div_refined(a.x, s, r), div_refined(a.y, s, r)};
+    return q;
+  }
+};
+#if BVQ_F16_COLS_DIV
+#define BVQ_DIVF16V DivF16RV
+#else
+#define BVQ_DIVF16V DivF16V
+#endif
+struct DivF16RV {
+  f2 s, r;
+  __device__ __forceinline__ f2 operator()(f2 a) const {
+    f2 q = {div_refined(a.x, s.x, r.x), div_refined(a.y, s.y, r.y)};
     return q;
   }
 };
@@ -391,8 +436,20 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
       return;
     }
   }
-  // (float16: the guarded reciprocal (DivF16) pays in the backward and in the column-mapped forward; here the
-  //  single division hides behind the loads and the extra branch cost 15 %: profiles/r01_f16_fastdiv.txt)
+  // float16: the refined reciprocal product (DivF16R: the exact float32 quotient in 4 instructions, no branch; the
+  // guarded reciprocal's wave-wide check cost 15 % here: profiles/r01_f16_fastdiv.txt)
+#ifndef BVQ_F16_FWD_EXACT
+  if constexpr (elem<CT>::id == BVQ_F16) {
+    if (f16_scale_ok(s)) {
+      const DivF16R div{s, 1.0f / s};
+      if (zp0)
+        BVQ_FWD_PRE(true, div);
+      else
+        BVQ_FWD_PRE(false, div);
+      return;
+    }
+  }
+#endif
   const DivExact div{s};
   if constexpr (sizeof(CT) == 2) {
     if (zp0) {
@@ -435,7 +492,7 @@ __device__ __forceinline__ void cols_fwd_rows(const ColsQuantArgs& a, const Cols
           if (a.pre_relu) xf = relu2(xf);
           f2 q2, res;
           if constexpr (FAST && elem<T>::id == BVQ_F16)
-            res = fwd_elem2<T, RM, ZP0>(xf, DivF16V{ln.s2[k / 2], r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax, false,
+            res = fwd_elem2<T, RM, ZP0>(xf, BVQ_DIVF16V{ln.s2[k / 2], r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax, false,
                                         mode, q2);
           else if constexpr (FAST)
             res = fwd_elem2<T, RM, ZP0>(xf, DivBf16V{r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax, false, mode, q2);
@@ -629,6 +686,16 @@ __global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant
         continue;
       }
     }
+    if constexpr (elem<T>::id == BVQ_F16) {
+      if (f16_scale_ok(s)) {
+        const DivF16R div{s, 1.0f / s};
+        if (a.pre_relu)
+          fused_quantize<T, RM, true>(xv, ok, yp, lane, div, s, qmin, qmax, mode);
+        else
+          fused_quantize<T, RM, false>(xv, ok, yp, lane, div, s, qmin, qmax, mode);
+        continue;
+      }
+    }
     const DivExact div{s};
     if (a.pre_relu)
       fused_quantize<T, RM, true>(xv, ok, yp, lane, div, s, qmin, qmax, mode);
@@ -798,7 +865,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
   ChunkCursor cur;
   cur.init(u, VEC, lane);
   const int64_t total = (int64_t)u.nrows * cur.cpr;
-  if constexpr (elem<CT>::id == BVQ_F16) {
+  if constexpr (elem<CT>::id == BVQ_F16 && !BVQ_F16_BWD_PIPE) {
     // float16: batches of two chunks per stream, loaded together, then worked on.  Its arithmetic (two converts per
     // rounding, the guarded reciprocal's wave-wide checks) is what bounds it, and the pipelined form below is
     // 7-20 % SLOWER here (profiles/r02_backward_variants.txt).
@@ -960,7 +1027,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96), amdgpu_
   }
   if constexpr (elem<CT>::id == BVQ_F16) {
     if (f16_scale_ok(s)) {
+#if BVQ_F16_BWD_DIV
+      const DivF16R div{s, 1.0f / s};
+#else
       const DivF16 div{s, 1.0f / s};
+#endif
       if (zp0)
         BVQ_BWD_PRE(true, div);
       else
@@ -1039,7 +1110,7 @@ __device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const Cols
           const f2 gf = widen2<T>(gv[j].v[k], gv[j].v[k + 1]);
           f2 d;
           if constexpr (FAST && elem<T>::id == BVQ_F16)
-            d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivF16V{ln.s2[k / 2], r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2],
+            d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, BVQ_DIVF16V{ln.s2[k / 2], r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2],
                                                        qmin, qmax, clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
           else if constexpr (FAST)
             d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivBf16V{r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax,
@@ -1609,6 +1680,28 @@ extern "C" int bvq_stats_fakequant_fwd(const bvq_quant_desc* d, const void* x, d
   }
   set_error("bvq_stats_fakequant_fwd: shape / layout not covered by the one-launch form");
   return BVQ_ERR_UNSUPPORTED;
+}
+
+// self-test of the float16 division (DivF16R): out[j * n_a + i] = the quotient the kernels compute for numerator
+// a[i] and scale s[j], so that a test can compare EVERY pair with a / s on the device itself
+__global__ __launch_bounds__(256) void selftest_div_f16r_kernel(const float* __restrict__ a, const float* __restrict__ sc,
+                                                                float* __restrict__ out, int32_t n_a) {
+  const float s = sc[blockIdx.y];
+  const float r = 1.0f / s;
+  for (int32_t i = blockIdx.x * 256 + threadIdx.x; i < n_a; i += gridDim.x * 256)
+    out[(int64_t)blockIdx.y * n_a + i] = div_refined(a[i], s, r);
+}
+
+extern "C" int bvq_selftest_div_f16r(const float* a, int32_t n_a, const float* scales, int32_t n_s, float* out,
+                                     bvq_stream_t stream) {
+  if (!a || !scales || !out || n_a < 1 || n_s < 1 || n_s > 65535) {
+    set_error("bvq_selftest_div_f16r: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  int nb = (n_a + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  selftest_div_f16r_kernel<<<dim3((unsigned)nb, (unsigned)n_s), dim3(256), 0, (hipStream_t)stream>>>(a, scales, out, n_a);
+  return check_launch("bvq_selftest_div_f16r");
 }
 
 #endif  // forward part

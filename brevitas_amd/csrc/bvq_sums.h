@@ -12,7 +12,9 @@ namespace bvq {
 // A per-tensor quantizer of a large activation has ~10^5 partials in its one channel; there the range is
 // cut into slices whose double sums go to mid0/mid1[c * splits + s], and a second launch (PT = double,
 // nob = 1, ppr = splits) finishes.  The order of additions is fixed either way: same bits on every run.
-constexpr int64_t kSumSlice = 4096;
+// (1024 = four partials per thread, loaded together: with 4096 a thread walked 16 dependent-latency loads one after
+//  the other and the per-tensor backward paid 30-90 us for its two finishing launches, profiles/r02_per_tensor_pieces.txt)
+constexpr int64_t kSumSlice = 1024;
 
 static inline int32_t sum_splits(int64_t partials_per_channel) {
   const int64_t s = (partials_per_channel + kSumSlice - 1) / kSumSlice;
@@ -72,16 +74,30 @@ __global__ __launch_bounds__(kBlock) void channel_sum_kernel(const PT* __restric
   const int64_t k0 = (int64_t)blockIdx.y * slice;
   const int64_t k1 = k0 + slice < n ? k0 + slice : n;
   double acc0 = 0.0, acc1 = 0.0;
-  for (int64_t k = k0 + threadIdx.x; k < k1; k += kBlock) {
-    int64_t unit;
-    if (nob == 1) {
-      unit = (int64_t)c * ppr + k;
-    } else {
-      const int64_t o = k / ppr, p = k - o * ppr;
-      unit = (o * channels + c) * ppr + p;
+  constexpr int kU = 4;  // loads in flight per thread; the additions keep their order
+  for (int64_t kb = k0 + threadIdx.x; kb < k1; kb += (int64_t)kU * kBlock) {
+    PT v0[kU], v1[kU];
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      const int64_t k = kb + (int64_t)j * kBlock;
+      int64_t unit = 0;
+      const bool in = k < k1;
+      if (in) {
+        if (nob == 1) {
+          unit = (int64_t)c * ppr + k;
+        } else {
+          const int64_t o = k / ppr, p = k - o * ppr;
+          unit = (o * channels + c) * ppr + p;
+        }
+      }
+      v0[j] = (in && part0) ? part0[unit] : (PT)0;
+      v1[j] = (in && part1) ? part1[unit] : (PT)0;
     }
-    if (part0) acc0 += (double)part0[unit];
-    if (part1) acc1 += (double)part1[unit];
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      acc0 += (double)v0[j];
+      acc1 += (double)v1[j];
+    }
   }
   sh[0][threadIdx.x] = acc0;
   sh[1][threadIdx.x] = acc1;

@@ -69,3 +69,53 @@ def test_reciprocal_multiply_is_exact_for_f16_over_f16_outside_the_subnormal_gua
             guarded += int(np.count_nonzero(g))
     assert bad == 0
     assert guarded > 0  # the guard is exercised (it is what makes the subnormal quotients right)
+
+
+def refined_quotient(a, s):
+    """DivF16R of brevitas_amd/csrc/bvq_fakequant.hip emulated exactly: q0 = RN32(a * r) with r = RN32(1 / s),
+    rem = fma(-q0, s, a), q = fma(rem, r, q0), then what v_div_fixup_f32 does for zero / infinite / NaN numerators
+    and for the sign.  The two fmas are evaluated in float64, where the first is exact (35-bit product, operands a
+    few binades apart) and the second is exact up to ONE rounding to 53 bits: the rare results that land exactly on
+    a float32 midpoint after that rounding are redone in rational arithmetic."""
+    from fractions import Fraction
+    a = a.astype(np.float32)
+    s = np.float32(s)
+    r = np.float32(1.0) / s
+    q0 = a * r
+    a64, s64, r64 = a.astype(np.float64), np.float64(s), np.float64(r)
+    rem64 = -q0.astype(np.float64) * s64 + a64
+    rem = rem64.astype(np.float32)
+    finite = np.isfinite(a) & (a != 0)
+    assert np.all(rem.astype(np.float64)[finite] == rem64[finite])  # the remainder of a faithful quotient is exact
+    t64 = rem.astype(np.float64) * r64 + q0.astype(np.float64)
+    q = t64.astype(np.float32)
+    mid = finite & ((t64.view(np.uint64) & np.uint64((1 << 29) - 1)) == np.uint64(1 << 28))
+    for i in np.nonzero(mid)[0]:
+        exact = Fraction(float(rem[i])) * Fraction(float(r)) + Fraction(float(q0[i]))
+        lo = np.nextafter(q[i], np.float32(-np.inf)) if Fraction(float(q[i])) > exact else q[i]
+        hi = np.nextafter(lo, np.float32(np.inf))
+        dl, dh = exact - Fraction(float(lo)), Fraction(float(hi)) - exact
+        if dl != dh:
+            q[i] = lo if dl < dh else hi
+        else:  # a true tie: to even
+            q[i] = lo if (int(np.float32(lo).view(np.uint32)) & 1) == 0 else hi
+    sign = np.signbit(a) ^ np.signbit(s)
+    out = np.where(sign, -np.abs(q), np.abs(q)).astype(np.float32)
+    out = np.where(a == 0, np.where(sign, np.float32(-0.0), np.float32(0.0)), out)
+    out = np.where(np.isinf(a), np.where(sign, np.float32(-np.inf), np.float32(np.inf)), out)
+    return np.where(np.isnan(a), np.float32(np.nan), out).astype(np.float32)
+
+
+def test_refined_reciprocal_product_is_the_ieee_quotient_for_f16_over_f16():
+    """DivF16R (float16 forward kernel): the float32 quotient itself, bit for bit, for every float16 numerator
+    (zeros, subnormals, infinities and NaNs included) -- two full binades of scales and a sample of the others
+    here; tests/test_gpu_fastdiv.py runs all 28 673 scales through the device code."""
+    a = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    bad = 0
+    with np.errstate(all='ignore'):
+        for s in f16_scales(full_binades=(-14, 0), stride=53):
+            got = refined_quotient(a, s)
+            want = a / s
+            same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+            bad += int(np.count_nonzero(~same))
+    assert bad == 0

@@ -1,4 +1,4 @@
-"""float16 backward fast path (DivF16, brevitas_amd/csrc/bvq_fakequant.hip): the arithmetic claim on every
+"""float16 fast paths (DivF16 and DivF16R, brevitas_amd/csrc/bvq_fakequant.hip): the arithmetic claims on every
 float16 numerator x every float16 scale in [2^-14, 2^14], and the kernels on inputs full of tiny and subnormal
 values (the quotients that must take the IEEE division) against the CPU oracle."""
 import numpy as np
@@ -27,6 +27,33 @@ def test_f16_reciprocal_claim_all_scales():
         guard = (ab > 0) & (ab < 0x38810000)
         bad += int(((fast != ref) & finite[None, :] & ~guard).sum())
     assert bad == 0, bad
+
+
+def test_f16_refined_division_is_the_ieee_quotient_for_every_pair():
+    """DivF16R: product with the correctly rounded reciprocal + one exact remainder step + v_div_fixup == a / s in
+    float32, bit for bit, for all 65536 float16 numerators (zeros, subnormals, infinities, NaNs included) x all
+    28673 float16 scales in [2^-14, 2^14] -- computed by the library's own device code (bvq_selftest_div_f16r)"""
+    from brevitas_amd import _native as nat
+    a = torch.arange(65536, dtype=torch.int32, device=DEV).to(torch.int16).view(torch.float16).float().contiguous()
+    scales = torch.arange(0x0400, 0x7400 + 1, dtype=torch.int32, device=DEV).to(torch.int16).view(torch.float16).float()
+    scales = scales[(scales >= 2.0 ** -14) & (scales <= 2.0 ** 14)].contiguous()
+    assert scales.numel() == 28 * 1024 + 1, scales.numel()
+    bad, nan_bad = 0, 0
+    for chunk in scales.split(1024):
+        got = nat.selftest_div_f16r(a, chunk.contiguous())
+        ref = a[None, :] / chunk[:, None]
+        nan = torch.isnan(ref)
+        nan_bad += int((torch.isnan(got) != nan).sum())
+        bad += int(((got.view(torch.int32) != ref.view(torch.int32)) & ~nan).sum())
+    assert bad == 0 and nan_bad == 0, (bad, nan_bad)
+    # the device's own a / s against numpy's on a sample (the reference above must itself be the IEEE quotient)
+    sub = scales[::997].cpu().numpy()
+    an = a.cpu().numpy()
+    with np.errstate(all='ignore'):
+        want = an[None, :] / sub[:, None]
+    got = nat.selftest_div_f16r(a, scales[::997].contiguous()).cpu().numpy()
+    ok = (got.view(np.int32) == want.view(np.int32)) | (np.isnan(got) & np.isnan(want))
+    assert ok.all()
 
 
 @pytest.mark.parametrize('layout', [(8, 16, 3136), (1, 1, 40000), (300, 64, 1), (64, 8, 49)],

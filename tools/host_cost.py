@@ -156,6 +156,8 @@ def main():
     rows.append(('  torch.empty_like(w)', per_call(lambda: torch.empty_like(w))))
     rows.append(('  nat.QuantDesc(...) construction', per_call(lambda: nat.QuantDesc(
         outer, ch, inner, code, code, code, nat.F32, 1, 0, -128.0, 127.0, 0, 0, 0, nat.OUT_DEQUANT, nat.PRE_NONE))))
+    rows.append(('full step again, last (the process is warm now)', per_call(step)))
+    rows.append(('full step again, 10000 calls', per_call(step, 10000)))
     print('%s %s int%d' % (list(shape), str(dt)[6:], bits))
     for name, us in rows:
         print('%8.1f us  %s' % (us, name))
