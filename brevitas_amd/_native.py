@@ -39,7 +39,8 @@ EXPORTS = (
     'bvq_kth_hist_offset', 'bvq_kth_begin', 'bvq_kth_hist', 'bvq_kth_pick', 'bvq_kth_finish', 'bvq_stat_bwd', 'bvq_tie_info_bytes', 'bvq_stat_tie_scan', 'bvq_stat_tie_apply', 'bvq_stat_tie_apply_dscale', 'bvq_fakequant_fwd', 'bvq_stats_fakequant_fwd_workspace_bytes', 'bvq_stats_fakequant_fwd',
     'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd_stats_workspace_bytes', 'bvq_fakequant_bwd_stats', 'bvq_fakequant_bwd',
     'bvq_learned_scale', 'bvq_fakequant_bwd_learned', 'bvq_variant_fwd', 'bvq_variant_bwd_workspace_bytes', 'bvq_variant_bwd',
-    'bvq_fakequant_fwd_bounds', 'bvq_fakequant_bwd_bounds', 'bvq_histc', 'bvq_absmax_scale_running', 'bvq_selftest_div_f16r')
+    'bvq_fakequant_fwd_bounds', 'bvq_fakequant_bwd_bounds', 'bvq_histc', 'bvq_absmax_scale_running', 'bvq_selftest_div_f16r',
+    'bvq_kthw_plan', 'bvq_kthw_begin', 'bvq_kthw_hist', 'bvq_kthw_pick', 'bvq_kthw_finish')
 
 
 class QuantDesc(ctypes.Structure):
@@ -114,6 +115,11 @@ def _load(path=None, strict=True):
         'bvq_kth_hist': (i32, [i32, i32, vp, i64, i64, i64, i32, vp, i64, vp]),
         'bvq_kth_pick': (i32, [i32, i64, i32, i32, dbl, vp, i64, vp]),
         'bvq_kth_finish': (i32, [i32, i32, i64, vp, vp, i64, vp]),
+        'bvq_kthw_plan': (i32, [i32, i32, i32, vp, vp]),
+        'bvq_kthw_begin': (i32, [i32, i32, vp, i64, vp]),
+        'bvq_kthw_hist': (i32, [i32, i32, vp, i64, i32, vp, i64, vp]),
+        'bvq_kthw_pick': (i32, [i32, i32, i32, i32, i64, dbl, vp, i64, vp]),
+        'bvq_kthw_finish': (i32, [i32, i32, vp, vp, i64, vp]),
         'bvq_tie_info_bytes': (i64, [i64]),
         'bvq_stat_tie_scan': (i32, [i32, i32, vp, vp, i64, i64, i64, vp, vp, vp]),
         'bvq_stat_tie_apply': (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
@@ -552,6 +558,50 @@ class KthSelectSteps:
         return out
 
 
+class KthWideSteps:
+    """the sharded selection of a whole-tensor statistic with the 15-bit first digit (include/bvq.h, bvq_kthw_*):
+    same interface as KthSelectSteps -- begin / hist(p) / pick(p) / finish, `passes`, `per_channel` -- for
+    brevitas_amd.distributed.sharded_kth_value; one pass for |x| of a 16-bit type, two otherwise"""
+
+    def __init__(self, x, abs_key, rule, q, k=0):
+        self.dev = require_device(x)
+        assert x.is_contiguous()
+        self.x, self.abs_key = x.reshape(-1), int(abs_key)
+        self.rule, self.q, self.k = int(rule), float(q), int(k)
+        self.per_channel = x.numel()
+        self.dt = dtype_code(x.dtype)
+        self.passes = int(lib.bvq_kthw_plan(self.abs_key, self.dt, -1, None, None))
+        self.wsb = int(lib.bvq_kth_workspace_bytes(self.dt, 1, 1, max(x.numel(), 1)))
+        if self.passes < 1 or self.wsb < 0:
+            raise BvqError('bvq_kthw_plan / bvq_kth_workspace_bytes: bad arguments')
+        self.ws = torch.empty(self.wsb, dtype=torch.uint8, device=self.dev)
+
+    def begin(self):
+        with _DeviceGuard(self.dev):
+            check(lib.bvq_kthw_begin(self.abs_key, self.dt, ptr(self.ws), self.wsb, stream_ptr(self.dev)), 'bvq_kthw_begin')
+
+    def hist(self, p):
+        """-> the counters of pass p to be summed over the shards (int32 view of the unsigned counters)"""
+        with _DeviceGuard(self.dev):
+            check(lib.bvq_kthw_hist(self.abs_key, self.dt, ptr(self.x) if self.x.numel() else None, self.x.numel(), p,
+                                    ptr(self.ws), self.wsb, stream_ptr(self.dev)), 'bvq_kthw_hist')
+        off, words = ctypes.c_int64(0), ctypes.c_int64(0)
+        lib.bvq_kthw_plan(self.abs_key, self.dt, p, ctypes.byref(off), ctypes.byref(words))
+        return self.ws[off.value:off.value + 4 * words.value].view(torch.int32)
+
+    def pick(self, p):
+        with _DeviceGuard(self.dev):
+            check(lib.bvq_kthw_pick(self.abs_key, self.dt, p, self.rule, self.k, self.q, ptr(self.ws), self.wsb,
+                                    stream_ptr(self.dev)), 'bvq_kthw_pick')
+
+    def finish(self):
+        out = torch.empty(1, dtype=self.x.dtype, device=self.dev)
+        with _DeviceGuard(self.dev):
+            check(lib.bvq_kthw_finish(self.abs_key, self.dt, ptr(out), ptr(self.ws), self.wsb, stream_ptr(self.dev)),
+                  'bvq_kthw_finish')
+        return out
+
+
 def running_stats_update(running, stat, momentum, first_batch):
     """in-place batch-norm style update of a running statistic (one launch)"""
     dev = require_device(running, stat)
@@ -708,7 +758,8 @@ def selftest_div_f16r(a, scales):
     out = torch.empty(scales.numel(), a.numel(), dtype=torch.float32, device=dev)
     with _DeviceGuard(dev):
         check(lib.bvq_selftest_div_f16r(ptr(a), a.numel(), ptr(scales), scales.numel(), ptr(out), stream_ptr(dev)),
-              'bvq_selftest_div_f16r')
+              'bvq_selftest_div_f16r',
+    'bvq_kthw_plan', 'bvq_kthw_begin', 'bvq_kthw_hist', 'bvq_kthw_pick', 'bvq_kthw_finish')
     return out
 
 

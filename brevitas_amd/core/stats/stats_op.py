@@ -153,7 +153,11 @@ class _KthValueFn(Function):
         else:
             from brevitas_amd.distributed import sharded_kth_value
             rule, q = rank
-            val = sharded_kth_value(nat.KthSelectSteps(xc.reshape(-1), outer, ch, inner, abs_key, rule, q), group)
+            # a whole-tensor statistic takes the 15-bit first digit (one read of a 16-bit |x|); the choice depends on
+            # the layout alone, so every shard makes the same one
+            steps = nat.KthWideSteps(xc.reshape(-1), abs_key, rule, q) if ch == 1 else \
+                nat.KthSelectSteps(xc.reshape(-1), outer, ch, inner, abs_key, rule, q)
+            val = sharded_kth_value(steps, group)
         ctx.layout = (outer, ch, inner, dim, abs_key)
         ctx.group = group
         ctx.save_for_backward(x, val)

@@ -1921,7 +1921,7 @@ static bool bwd_stats_supported(const bvq_quant_desc* d, int64_t& units, int64_t
   }
   units = bwd_units(d);
   per_channel = units / d->channels;
-  return per_channel <= kSumSlice;  // one finishing stage
+  return per_channel <= 4096;  // one workgroup of bwd_stats_finish_kernel per channel walks them
 }
 
 extern "C" int64_t bvq_fakequant_bwd_stats_workspace_bytes(const bvq_quant_desc* d) {

@@ -241,13 +241,16 @@ __global__ void kth_zero_kernel(uint32_t* p, int32_t n) {
   if (i < n) p[i] = 0;
 }
 
+// head: elements in front of x (x - head .. x) that precede the first 16-byte boundary of the caller's buffer
 template <typename T, bool ABS, bool NT>
 __global__ __launch_bounds__(kBlock15) void kth_hist15_kernel(const T* __restrict__ x, int64_t n, int32_t shift,
-                                                             uint32_t* __restrict__ hist) {
+                                                             uint32_t* __restrict__ hist, int32_t head = 0) {
   constexpr int VEC = elem<T>::vec;
   __shared__ uint32_t h[kBins15];
   for (int b = threadIdx.x; b < kBins15; b += kBlock15) h[b] = 0;
   __syncthreads();
+  if (blockIdx.x == 0 && (int32_t)threadIdx.x < head)
+    atomicAdd(&h[sel_key<T, ABS>(x[(int64_t)threadIdx.x - head]) >> shift], 1u);
   const int64_t chunks = n / VEC;
   const int64_t stride = (int64_t)gridDim.x * kBlock15;
   for (int64_t c = (int64_t)blockIdx.x * kBlock15 + threadIdx.x; c < chunks; c += stride * kSelUnroll) {
@@ -297,7 +300,7 @@ __device__ __forceinline__ void low_count(uint32_t key, uint32_t want, int32_t s
 template <typename T, bool ABS, bool NT, bool SMALL>
 __global__ __launch_bounds__(kBlock) void kth_low_kernel(const T* __restrict__ x, int64_t n, int32_t shift,
                                                         const uint32_t* __restrict__ sel, uint32_t* __restrict__ gh,
-                                                        int32_t nk) {
+                                                        int32_t nk, int32_t head = 0) {
   // nk (1 or 2) ranks are served by the same read: rank i has its own chosen bin sel[i] and its own counters
   constexpr int VEC = elem<T>::vec;
   __shared__ uint32_t lh[SMALL ? 2 * kBins : 1];
@@ -337,6 +340,11 @@ __global__ __launch_bounds__(kBlock) void kth_low_kernel(const T* __restrict__ x
     low_count(key, want, shift, lowmask, ghist);
     if (nk > 1) low_count(key, want2, shift, lowmask, ghist + hstride);
   }
+  if (blockIdx.x == 0 && (int32_t)threadIdx.x < head) {  // (a separate branch: low_count's ballots see whole waves)
+    const uint32_t key = sel_key<T, ABS>(x[(int64_t)threadIdx.x - head]);
+    low_count(key, want, shift, lowmask, ghist);
+    if (nk > 1) low_count(key, want2, shift, lowmask, ghist + hstride);
+  }
   if constexpr (SMALL) {
     __syncthreads();
     for (int i = 0; i < nk; ++i)
@@ -349,11 +357,15 @@ __global__ __launch_bounds__(kBlock) void kth_low_kernel(const T* __restrict__ x
 
 // one workgroup: the bin of hist[0, nbins) that holds the k-th (1-indexed) element; sel[0] <- sel[0] << bits | bin
 // (sel[0] starts at 0), krem[0] <- rank inside that bin.  first: k comes as an argument, else from krem[0].
+// rule / q (first pick only): the rank from the total count of the histogram -- the GLOBAL element count once the
+// shards' histograms have been summed -- instead of k_arg
 __global__ __launch_bounds__(kBlock15) void kth_pick_wide_kernel(const uint32_t* __restrict__ hist, int32_t nbins,
                                                                 int32_t bits, int32_t first, int64_t k_arg,
-                                                                uint32_t* __restrict__ sel, int64_t* __restrict__ krem) {
+                                                                uint32_t* __restrict__ sel, int64_t* __restrict__ krem,
+                                                                int32_t rule = BVQ_KTH_EXPLICIT, double q = 0.0) {
   __shared__ int64_t part[kBlock15];
   __shared__ int64_t before_me[kBlock15];
+  __shared__ int64_t total;
   const int per = (nbins + kBlock15 - 1) / kBlock15;
   const int lo = threadIdx.x * per, hi = lo + per < nbins ? lo + per : nbins;
   int64_t mine = 0;
@@ -366,9 +378,10 @@ __global__ __launch_bounds__(kBlock15) void kth_pick_wide_kernel(const uint32_t*
       before_me[t] = run;
       run += part[t];
     }
+    total = run;
   }
   __syncthreads();
-  const int64_t k = first ? k_arg : krem[0];
+  const int64_t k = first ? (rule != BVQ_KTH_EXPLICIT ? rank_from_rule(rule, q, total) : k_arg) : krem[0];
   const uint32_t prev = first ? 0u : sel[0];
   __syncthreads();  // everyone has read krem / sel before the owner overwrites them
   int64_t run = before_me[threadIdx.x];
@@ -647,6 +660,174 @@ static int wide_select(int abs_key, int dtype, const void* x, int64_t n, const i
 #undef BVQ_WIDE_DT
 #undef BVQ_WIDE
   return check_launch("bvq_kth_value/wide");
+}
+
+// ---- the per-tensor route in steps, for a batch-sharded tensor (include/bvq.h, bvq_kthw_*) --------------------
+struct WideWs {
+  uint32_t* hist;  // [32768]
+  uint32_t* low;   // [2][1 << 17]
+  int64_t* krem;   // [2]
+  uint32_t* sel;   // [2]
+};
+static WideWs wide_ws(int dtype, void* workspace) {
+  WideWs w;
+  char* base = reinterpret_cast<char*>(workspace) + (sel_steps_bytes(dtype, 1) + 255) / 256 * 256;
+  w.hist = reinterpret_cast<uint32_t*>(base);
+  w.low = w.hist + kBins15;
+  w.krem = reinterpret_cast<int64_t*>(w.low + 2 * ((int64_t)1 << kLowBitsMax));
+  w.sel = reinterpret_cast<uint32_t*>(w.krem + 2);
+  return w;
+}
+static int wide_shift(int abs_key, int dtype) { return (dtype == BVQ_F32 ? 32 : 16) - (abs_key ? 1 : 0) - 15; }
+
+static int kthw_check(const char* who, int dtype, const void* workspace, int64_t workspace_bytes) {
+  if (dtype < BVQ_F32 || dtype > BVQ_F16) {
+    set_error("%s: bad dtype", who);
+    return BVQ_ERR_INVALID;
+  }
+  if (!workspace || workspace_bytes < sel_workspace_bytes(dtype, 1)) {
+    set_error("%s: workspace %lld < %lld bytes", who, (long long)workspace_bytes, (long long)sel_workspace_bytes(dtype, 1));
+    return BVQ_ERR_WORKSPACE;
+  }
+  return BVQ_OK;
+}
+
+extern "C" int bvq_kthw_plan(int abs_key, int dtype, int pass, int64_t* hist_offset_bytes, int64_t* hist_words) {
+  if (dtype < BVQ_F32 || dtype > BVQ_F16) return -1;
+  const int shift = wide_shift(abs_key, dtype);
+  const int passes = shift ? 2 : 1;
+  if (pass < 0 || pass >= passes) return passes;  // (a query for the pass count alone)
+  const int64_t base = (sel_steps_bytes(dtype, 1) + 255) / 256 * 256;
+  if (hist_offset_bytes) *hist_offset_bytes = base + (pass ? (int64_t)kBins15 * (int64_t)sizeof(uint32_t) : 0);
+  if (hist_words) *hist_words = pass ? ((int64_t)1 << shift) : kBins15;
+  return passes;
+}
+
+extern "C" int bvq_kthw_begin(int abs_key, int dtype, void* workspace, int64_t workspace_bytes, bvq_stream_t stream) {
+  int rc = kthw_check("bvq_kthw_begin", dtype, workspace, workspace_bytes);
+  if (rc) return rc;
+  const WideWs w = wide_ws(dtype, workspace);
+  const int shift = wide_shift(abs_key, dtype);
+  const int32_t words = kBins15 + (shift ? (int32_t)((int64_t)1 << shift) : 0);
+  kth_zero_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(w.hist, words);
+  return check_launch("bvq_kthw_begin");
+}
+
+extern "C" int bvq_kthw_hist(int abs_key, int dtype, const void* x, int64_t n, int pass, void* workspace,
+                             int64_t workspace_bytes, bvq_stream_t stream) {
+  int rc = kthw_check("bvq_kthw_hist", dtype, workspace, workspace_bytes);
+  if (rc) return rc;
+  const int shift = wide_shift(abs_key, dtype);
+  if (n < 0 || pass < 0 || pass >= (shift ? 2 : 1)) {
+    set_error("bvq_kthw_hist: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  if (n == 0) return BVQ_OK;  // an empty shard adds nothing
+  if (n > kSelMaxCount) {
+    set_error("bvq_kthw_hist: %lld elements; the counters are 32-bit (limit 2^32 - 1 over all shards)", (long long)n);
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  if (!x) {
+    set_error("bvq_kthw_hist: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const WideWs w = wide_ws(dtype, workspace);
+  // the kernels take 16-byte chunks from an aligned address: the elements in front of it are counted one by one
+  const int es = dtype_size(dtype);
+  int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) / (uintptr_t)es);
+  if (head > n) head = n;
+  const char* xa = reinterpret_cast<const char*>(x) + head * es;
+  const int64_t na = n - head;
+  const bool nt = n * (int64_t)es >= nt_threshold_bytes();
+  // few elements: few workgroups (each one flushes its own 32768-bin histogram)
+  const int64_t chunks = na / (16 / es);
+  unsigned g15 = (unsigned)((chunks + kBlock15 * kSelUnroll - 1) / (kBlock15 * kSelUnroll));
+  g15 = g15 < 1 ? 1 : (g15 > 256 ? 256 : g15);
+  unsigned glow = (unsigned)((chunks + kBlock * kSelUnroll - 1) / (kBlock * kSelUnroll));
+  glow = glow < 1 ? 1 : (glow > 2048 ? 2048 : glow);
+#define BVQ_KTHW(T, ABS)                                                                                              \
+  do {                                                                                                                \
+    const T* xp = reinterpret_cast<const T*>(xa);                                                                     \
+    if (pass == 0) {                                                                                                  \
+      if (nt)                                                                                                         \
+        kth_hist15_kernel<T, ABS, true><<<dim3(g15), dim3(kBlock15), 0, st>>>(xp, na, shift, w.hist, (int32_t)head);  \
+      else                                                                                                            \
+        kth_hist15_kernel<T, ABS, false><<<dim3(g15), dim3(kBlock15), 0, st>>>(xp, na, shift, w.hist, (int32_t)head); \
+    } else if (shift <= kDigitBits) {                                                                                 \
+      kth_low_kernel<T, ABS, false, true><<<dim3(glow > 1024 ? 1024 : glow), dim3(kBlock), 0, st>>>(                  \
+          xp, na, shift, w.sel, w.low, 1, (int32_t)head);                                                             \
+    } else if (nt) {                                                                                                  \
+      kth_low_kernel<T, ABS, true, false><<<dim3(glow), dim3(kBlock), 0, st>>>(xp, na, shift, w.sel, w.low, 1,        \
+                                                                             (int32_t)head);                         \
+    } else {                                                                                                          \
+      kth_low_kernel<T, ABS, false, false><<<dim3(glow), dim3(kBlock), 0, st>>>(xp, na, shift, w.sel, w.low, 1,       \
+                                                                              (int32_t)head);                        \
+    }                                                                                                                 \
+  } while (0)
+#define BVQ_KTHW_DT(ABS)        \
+  do {                          \
+    if (dtype == BVQ_F32)       \
+      BVQ_KTHW(float, ABS);     \
+    else if (dtype == BVQ_BF16) \
+      BVQ_KTHW(bf16_t, ABS);    \
+    else                        \
+      BVQ_KTHW(f16_t, ABS);     \
+  } while (0)
+  if (abs_key)
+    BVQ_KTHW_DT(true);
+  else
+    BVQ_KTHW_DT(false);
+#undef BVQ_KTHW_DT
+#undef BVQ_KTHW
+  return check_launch("bvq_kthw_hist");
+}
+
+extern "C" int bvq_kthw_pick(int abs_key, int dtype, int pass, int rule, int64_t k, double q, void* workspace,
+                             int64_t workspace_bytes, bvq_stream_t stream) {
+  int rc = kthw_check("bvq_kthw_pick", dtype, workspace, workspace_bytes);
+  if (rc) return rc;
+  const int shift = wide_shift(abs_key, dtype);
+  if (pass < 0 || pass >= (shift ? 2 : 1) || rule < BVQ_KTH_EXPLICIT || rule > BVQ_KTH_LOW ||
+      (pass == 0 && rule == BVQ_KTH_EXPLICIT && k < 1) || (pass == 0 && rule != BVQ_KTH_EXPLICIT && !(q >= 0.0 && q <= 100.0))) {
+    set_error("bvq_kthw_pick: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  const WideWs w = wide_ws(dtype, workspace);
+  if (pass == 0)
+    kth_pick_wide_kernel<<<dim3(1), dim3(kBlock15), 0, (hipStream_t)stream>>>(w.hist, kBins15, 15, 1, k, w.sel, w.krem,
+                                                                             rule, q);
+  else
+    kth_pick_wide_kernel<<<dim3(1), dim3(kBlock15), 0, (hipStream_t)stream>>>(w.low, 1 << shift, shift, 0, 0, w.sel,
+                                                                             w.krem);
+  return check_launch("bvq_kthw_pick");
+}
+
+extern "C" int bvq_kthw_finish(int abs_key, int dtype, void* out, void* workspace, int64_t workspace_bytes,
+                               bvq_stream_t stream) {
+  int rc = kthw_check("bvq_kthw_finish", dtype, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!out) {
+    set_error("bvq_kthw_finish: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const WideWs w = wide_ws(dtype, workspace);
+#define BVQ_KTHW_STORE(T)                                             \
+  do {                                                                \
+    if (abs_key)                                                      \
+      kth_store_kernel<T, true><<<dim3(1), dim3(64), 0, st>>>(w.sel, out, 1);  \
+    else                                                              \
+      kth_store_kernel<T, false><<<dim3(1), dim3(64), 0, st>>>(w.sel, out, 1); \
+  } while (0)
+  if (dtype == BVQ_F32)
+    BVQ_KTHW_STORE(float);
+  else if (dtype == BVQ_BF16)
+    BVQ_KTHW_STORE(bf16_t);
+  else
+    BVQ_KTHW_STORE(f16_t);
+#undef BVQ_KTHW_STORE
+  return check_launch("bvq_kthw_finish");
 }
 
 extern "C" int bvq_kth_value(int abs_key, int dtype, const void* x, int64_t outer, int64_t channels,

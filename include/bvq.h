@@ -303,6 +303,33 @@ int bvq_kth_pick(int dtype, int64_t channels, int pass, int rule, double q, void
 int bvq_kth_finish(int abs_key, int dtype, int64_t channels, void* out, void* workspace,
                    int64_t workspace_bytes, bvq_stream_t stream);
 
+/* The sharded selection of a WHOLE-TENSOR statistic (one channel; the default Int8ActPerTensorFloat's
+ * AbsPercentile, B/quant/base.py:68-75) with the 15-bit first digit of bvq_kth_value's per-tensor route: the first
+ * pass histograms the top 15 key bits (32768 counters held in LDS) -- for |x| of a 16-bit type that is the whole key
+ * and the only pass; otherwise a second pass counts the remaining 1 / 16 / 17 bits of the elements in the chosen
+ * bin.  One read and one all-reduce for bf16 / f16 |x| (two of each with the 11-bit passes above), two for
+ * float32 (three).  Same calling pattern, same rank rules, same 32-bit counter limit:
+ *
+ *   passes = bvq_kthw_plan(abs_key, dtype, -1, NULL, NULL);
+ *   bvq_kthw_begin(...);
+ *   for (pass = 0; pass < passes; ++pass) {
+ *     bvq_kthw_hist(..., pass, ...);   bvq_kthw_plan(abs_key, dtype, pass, &offset, &words);
+ *     all-reduce(SUM) the `words` uint32 counters at workspace + offset;
+ *     bvq_kthw_pick(..., pass, ...);
+ *   }
+ *   bvq_kthw_finish(...);   -> out[1]
+ *
+ * x: n contiguous elements of this shard (any alignment, n may be 0).  Workspace: bvq_kth_workspace_bytes(dtype,
+ * 1, 1, n).  rule / k / q are read by the pick of pass 0 only. */
+int bvq_kthw_plan(int abs_key, int dtype, int pass, int64_t* hist_offset_bytes, int64_t* hist_words);
+int bvq_kthw_begin(int abs_key, int dtype, void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
+int bvq_kthw_hist(int abs_key, int dtype, const void* x, int64_t n, int pass, void* workspace,
+                  int64_t workspace_bytes, bvq_stream_t stream);
+int bvq_kthw_pick(int abs_key, int dtype, int pass, int rule, int64_t k, double q, void* workspace,
+                  int64_t workspace_bytes, bvq_stream_t stream);
+int bvq_kthw_finish(int abs_key, int dtype, void* out, void* workspace, int64_t workspace_bytes,
+                    bvq_stream_t stream);
+
 /* which elements attain the statistic */
 typedef enum bvq_match_kind {
   BVQ_MATCH_ABS = 0,   /* |x| == stat, deposit scaled by sgn(x): torch.max(torch.abs(x)) (AbsMax)   */

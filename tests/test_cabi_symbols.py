@@ -127,3 +127,15 @@ def test_python_binding_signatures_match_the_header():
             (fn.restype in (ctypes.c_int, ctypes.c_int32) and ret == 'int'), (name, fn.restype, ret)
         checked += 1
     assert checked >= 40
+
+
+def test_headline_layout_takes_the_two_launch_backward():
+    """host-side coverage rules: the stats-scaled per-channel backward of the headline activation (and of conv / linear
+    weights) must be served by bvq_fakequant_bwd_stats (kernel + one finishing launch), not by the general route"""
+    from brevitas_amd import _native as nat
+    for dt in (nat.BF16, nat.F16, nat.F32):
+        for outer, ch, inner in ((256, 512, 3136), (1, 512, 4608), (1, 8192, 8192), (128, 1024, 196)):
+            d = nat.QuantDesc(outer, ch, inner, dt, dt, dt, nat.F32, 1, 0, -128.0, 127.0, 0, 0, 0, 0, 0)
+            assert nat.lib.bvq_fakequant_bwd_stats_workspace_bytes(ctypes.byref(d)) > 0, (dt, outer, ch, inner)
+    d = nat.QuantDesc(1, 1, 1 << 20, nat.BF16, nat.BF16, nat.F32, nat.F32, 0, 0, -128.0, 127.0, 0, 0, 0, 0, 0)
+    assert nat.lib.bvq_fakequant_bwd_stats_workspace_bytes(ctypes.byref(d)) == 0  # per-tensor: the general route

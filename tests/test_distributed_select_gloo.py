@@ -88,6 +88,28 @@ class NumpySelectSteps:
         return torch.tensor([_unkey(self.prefix, self.abs_key)])
 
 
+class NumpyWideSteps(NumpySelectSteps):
+    """stand-in for brevitas_amd._native.KthWideSteps over one float32 shard: a 15-bit first digit, then the
+    remaining 16 (|x|) or 17 bits in ONE pass -- the histogram the shards sum has a different size per pass"""
+
+    def __init__(self, x, abs_key, rule, q):
+        super().__init__(x, abs_key, rule, q)
+        self.key_bits = 31 if abs_key else 32
+        self.passes = 2
+
+    def _bits(self, p):
+        return 15 if p == 0 else self.key_bits - 15
+
+    def hist(self, p):
+        bits = self._bits(p)
+        shift = self.key_bits - self.done - bits
+        sel = self.keys if p == 0 else self.keys[(self.keys >> np.uint64(shift + bits)) == np.uint64(self.prefix)]
+        digits = ((sel >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64)
+        counts = np.bincount(digits, minlength=1 << bits).astype(np.uint32)
+        self.h = torch.from_numpy(counts.view(np.int32).copy())
+        return self.h
+
+
 def _worker(rank, world, port, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -109,6 +131,8 @@ def _worker(rank, world, port, q):
                     for qq in qs:
                         steps = NumpySelectSteps(mine, abs_key, rule, qq)
                         got = float(sharded_kth_value(steps, dist.group.WORLD))
+                        wide = float(sharded_kth_value(NumpyWideSteps(mine, abs_key, rule, qq), dist.group.WORLD))
+                        assert wide == got, (split, abs_key, rule, qq, wide, got)
                         n = full.numel()
                         k = int(math.floor(.01 * qq * n + 0.5)) if rule == 1 else int(math.ceil(.01 * qq * n))
                         src = full.abs() if abs_key else full

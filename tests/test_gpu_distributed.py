@@ -178,3 +178,63 @@ def test_scale_from_stat_equals_the_three_torch_ops(dtype):
     # 0-dim promotion: float32 scale of a 16-bit statistic
     stat, scale = nat.scale_from_stat(stat32[:1].contiguous(), dtype, None, 127.0, torch.float32)
     assert scale.dtype == torch.float32 and float(scale) == float(stat32[0].to(dtype).float() / 127.0)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32], ids=['bf16', 'f16', 'f32'])
+def test_wide_stepwise_select_equals_kth_value(nccl_world1, dtype):
+    """bvq_kthw_* (15-bit first digit, whole-tensor statistic) through the RCCL all-reduce == bvq_kth_value ==
+    torch.kthvalue: both key kinds, both rank rules, an explicit rank, a buffer that does not start on a 16-byte
+    boundary, a tiny one"""
+    import math
+
+    from brevitas_amd import _native as nat
+    from brevitas_amd.distributed import sharded_kth_value
+    torch.manual_seed(123456)
+    base = torch.randn(70001, device=DEV).to(dtype)
+    base[100:180] = 0.5
+    for x in (base, base[3:], base[1:40], base[5:6]):
+        n = x.numel()
+        for abs_key in (True, False):
+            src = x.float().abs() if abs_key else x.float()
+            assert nat.KthWideSteps(x, abs_key, nat.KTH_HIGH, 50.0).passes == (1 if abs_key and dtype != torch.float32 else 2)
+            for rule, qs in ((nat.KTH_HIGH, (99.999, 50.0, 0.3)), (nat.KTH_LOW, (0.001, 25.0, 100.0))):
+                for q in qs:
+                    k = int(math.floor(.01 * q * n + 0.5)) if rule == nat.KTH_HIGH else int(math.ceil(.01 * q * n))
+                    k = min(max(k, 1), n)
+                    got = sharded_kth_value(nat.KthWideSteps(x, abs_key, rule, q), nccl_world1)
+                    assert torch.equal(got.float().reshape(()), src.kthvalue(k).values), (n, abs_key, rule, q)
+            k = min(17, n)
+            got = sharded_kth_value(nat.KthWideSteps(x, abs_key, nat.KTH_EXPLICIT, 0.0, k=k), nccl_world1)
+            assert torch.equal(got.float().reshape(()), src.kthvalue(k).values)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32], ids=['bf16', 'f32'])
+@pytest.mark.parametrize('split', [0, 1, 4099, 50000], ids=lambda s: 'split%d' % s)
+def test_wide_stepwise_select_over_two_shards_on_one_device(dtype, split):
+    """the protocol with two shards held by one process: the counters of both shards are summed by hand where the
+    all-reduce would do it -> the k-th value of the concatenation, from either shard's workspace"""
+    from brevitas_amd import _native as nat
+    torch.manual_seed(123456 + split)
+    full = torch.randn(50000, device=DEV).to(dtype)
+    full[[3, 49000]] = 2.5
+    full[200:260] = -0.25
+    shards = [full[:split].contiguous(), full[split:].contiguous()]
+    for abs_key, rule, q in ((True, nat.KTH_HIGH, 99.999), (True, nat.KTH_HIGH, 50.0), (False, nat.KTH_LOW, 0.1),
+                             (False, nat.KTH_HIGH, 75.0)):
+        steps = [nat.KthWideSteps(s, abs_key, rule, q) for s in shards]
+        for s in steps:
+            s.begin()
+        for p in range(steps[0].passes):
+            hs = [s.hist(p) for s in steps]
+            total = hs[0] + hs[1]
+            for h in hs:
+                h.copy_(total)
+            for s in steps:
+                s.pick(p)
+        vals = [s.finish() for s in steps]
+        n = full.numel()
+        import math
+        k = int(math.floor(.01 * q * n + 0.5)) if rule == nat.KTH_HIGH else int(math.ceil(.01 * q * n))
+        src = full.float().abs() if abs_key else full.float()
+        want = src.kthvalue(min(max(k, 1), n)).values
+        assert torch.equal(vals[0].float().reshape(()), want) and torch.equal(vals[1], vals[0]), (abs_key, rule, q)
