@@ -758,8 +758,7 @@ def selftest_div_f16r(a, scales):
     out = torch.empty(scales.numel(), a.numel(), dtype=torch.float32, device=dev)
     with _DeviceGuard(dev):
         check(lib.bvq_selftest_div_f16r(ptr(a), a.numel(), ptr(scales), scales.numel(), ptr(out), stream_ptr(dev)),
-              'bvq_selftest_div_f16r',
-    'bvq_kthw_plan', 'bvq_kthw_begin', 'bvq_kthw_hist', 'bvq_kthw_pick', 'bvq_kthw_finish')
+              'bvq_selftest_div_f16r')
     return out
 
 

@@ -1058,6 +1058,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96), amdgpu_
 #ifndef BVQ_COLS_BWD_WAVES
 #define BVQ_COLS_BWD_WAVES 4  // occupancy floor handed to the register allocator
 #endif
+
 template <typename T, int RM, bool NT, bool ZP0, bool FAST>
 __device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const ColsLane<T>& ln, float qmin, float qmax) {
   constexpr int VEC = elem<T>::vec;
@@ -1083,10 +1084,61 @@ __device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const Cols
 #pragma unroll
   for (int k = 0; k < (kSame16 ? 1 : VEC); ++k)
     first[k] = ln.row0 < ln.row_end ? (uint32_t)ln.row0 : ~0u;  // an all-zero column attains its 0 in the first row
-  uint32_t it = 0;  // row counter of this lane (wave-uniform)
   const bool ties = a.tie_stat != nullptr;
   const bool clamp_ste = a.clamp_ste != 0;
   const int mode = a.round_mode;
+  // the work on one row of this lane's columns: rr = the row, cnt = how many rows this lane has seen before it
+  auto row_work = [&](const vec_t<T, VEC>& xr, const vec_t<T, VEC>& gr, int64_t rr, uint32_t cnt) {
+    vec_t<T, VEC> dv;
+#pragma unroll
+    for (int k = 0; k < VEC; k += 2) {
+      const f2 xraw = widen2<T>(xr.v[k], xr.v[k + 1]);
+      const f2 xin = a.pre_relu ? relu2(xraw) : xraw;
+      const f2 gf = widen2<T>(gr.v[k], gr.v[k + 1]);
+      f2 d;
+      if constexpr (FAST && elem<T>::id == BVQ_F16)
+        d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, BVQ_DIVF16V{ln.s2[k / 2], r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2],
+                                                   qmin, qmax, clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
+      else if constexpr (FAST)
+        d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivBf16V{r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax,
+                                                   clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
+      else
+        d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivExactV{ln.s2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin,
+                                                   qmax, clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
+      if (a.pre_relu) d = xraw > splat2(0.f) ? d : splat2(0.f);
+      pack2<T>(d, dv.v[k], dv.v[k + 1]);
+    }
+    store_vec<T, VEC, NT>(dxp + rr * a.p.L, dv);
+    if (ties) {
+      if constexpr (kSame16) {
+        const vec_t<uint32_t, VEC / 2> w = __builtin_bit_cast(vec_t<uint32_t, VEC / 2>, xr);
+        const uint32_t inv = 0xffffu - cnt;
+#pragma unroll
+        for (int k = 0; k < VEC / 2; ++k) {
+          // relu: negative patterns (sign bit set) count as 0; otherwise the sign bits are masked below
+          const uint32_t w2 = a.pre_relu ? __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
+                                               __builtin_bit_cast(i16x2, w.v[k]), i16x2{0, 0}))
+                                         : w.v[k];
+          const uint32_t klo = ((w2 << 16) & 0x7fff0000u) | inv, khi = (w2 & 0x7fff0000u) | inv;
+          um[2 * k] = klo > um[2 * k] ? klo : um[2 * k];
+          um[2 * k + 1] = khi > um[2 * k + 1] ? khi : um[2 * k + 1];
+        }
+      } else {
+        const uint32_t rr32 = (uint32_t)rr;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const uint32_t b = a.pre_relu ? pre_abs_bits<T, true>(xr.v[k]) : pre_abs_bits<T, false>(xr.v[k]);
+          const bool gt = b > um[k];
+          um[k] = gt ? b : um[k];
+          first[k] = gt ? rr32 : first[k];
+        }
+      }
+    }
+  };
+  // (a software-pipelined walk like the row-mapped backward's was measured here: with this kernel's per-column state it
+  //  spills at depth 4 and is within +-2 % of these batches at depth 2-3 with a lower occupancy floor, 10 % slower for
+  //  float32: profiles/r02_column_mapped.txt)
+  uint32_t it = 0;  // row counter of this lane (wave-uniform)
   for (int64_t r = ln.row0; r < ln.row_end; r += (int64_t)kU * a.p.rpp) {
     vec_t<T, VEC> xv[kU], gv[kU];
     bool ok[kU];
@@ -1099,56 +1151,8 @@ __device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const Cols
       gv[j] = load_vec<T, VEC, NT>(gp + lo);
     }
 #pragma unroll
-    for (int j = 0; j < kU; ++j) {
-      if (ok[j]) {
-        const int64_t rr = r + (int64_t)j * a.p.rpp;
-        vec_t<T, VEC> dv;
-#pragma unroll
-        for (int k = 0; k < VEC; k += 2) {
-          const f2 xraw = widen2<T>(xv[j].v[k], xv[j].v[k + 1]);
-          const f2 xin = a.pre_relu ? relu2(xraw) : xraw;
-          const f2 gf = widen2<T>(gv[j].v[k], gv[j].v[k + 1]);
-          f2 d;
-          if constexpr (FAST && elem<T>::id == BVQ_F16)
-            d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, BVQ_DIVF16V{ln.s2[k / 2], r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2],
-                                                       qmin, qmax, clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
-          else if constexpr (FAST)
-            d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivBf16V{r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax,
-                                                       clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
-          else
-            d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivExactV{ln.s2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin,
-                                                       qmax, clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
-          if (a.pre_relu) d = xraw > splat2(0.f) ? d : splat2(0.f);
-          pack2<T>(d, dv.v[k], dv.v[k + 1]);
-        }
-        store_vec<T, VEC, NT>(dxp + rr * a.p.L, dv);
-        if (ties) {
-          if constexpr (kSame16) {
-            const vec_t<uint32_t, VEC / 2> w = __builtin_bit_cast(vec_t<uint32_t, VEC / 2>, xv[j]);
-            const uint32_t inv = 0xffffu - (it + (uint32_t)j);
-#pragma unroll
-            for (int k = 0; k < VEC / 2; ++k) {
-              // relu: negative patterns (sign bit set) count as 0; otherwise the sign bits are masked below
-              const uint32_t w2 = a.pre_relu ? __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
-                                                   __builtin_bit_cast(i16x2, w.v[k]), i16x2{0, 0}))
-                                             : w.v[k];
-              const uint32_t klo = ((w2 << 16) & 0x7fff0000u) | inv, khi = (w2 & 0x7fff0000u) | inv;
-              um[2 * k] = klo > um[2 * k] ? klo : um[2 * k];
-              um[2 * k + 1] = khi > um[2 * k + 1] ? khi : um[2 * k + 1];
-            }
-          } else {
-            const uint32_t rr32 = (uint32_t)rr;
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-              const uint32_t b = a.pre_relu ? pre_abs_bits<T, true>(xv[j].v[k]) : pre_abs_bits<T, false>(xv[j].v[k]);
-              const bool gt = b > um[k];
-              um[k] = gt ? b : um[k];
-              first[k] = gt ? rr32 : first[k];
-            }
-          }
-        }
-      }
-    }
+    for (int j = 0; j < kU; ++j)
+      if (ok[j]) row_work(xv[j], gv[j], r + (int64_t)j * a.p.rpp, it + (uint32_t)j);
     it += kU;
   }
   // this lane's partial row of the [prows][L] arrays
