@@ -20,3 +20,6 @@ VERBOSE = _env_flag('BREVITAS_VERBOSE', False)
 SCALAR_OPERAND_MODE = os.environ.get('BREVITAS_AMD_SCALAR_OPERAND_MODE', 'device')
 # fused fast paths of RescalingIntQuant (recognised quantizer graphs); 0 forces the generic composition
 FUSED_PATHS = _env_flag('BREVITAS_AMD_FUSED', True)
+# the weight quantizer's autograd node in C++ (brevitas_amd/_bvq_autograd.so, host glue over the same C-ABI calls);
+# 0: always the Python torch.autograd.Function
+CPP_AUTOGRAD = _env_flag('BREVITAS_AMD_CPP_AUTOGRAD', True)

@@ -443,47 +443,121 @@ class StatsFakeQuantFn(Function):
     @staticmethod
     def backward(ctx, gy, gscale, _gstat):
         xc, scale, zp, stat, int_threshold = ctx.saved_tensors
-        desc, sp = ctx.desc, ctx.sp
-        ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
-        if gy is None:  # only `scale` was used downstream
-            if gscale is None:
-                return None, None, None, None, None, None, None, None, None, None
-            gy = torch.zeros(xc.shape, dtype=ct, device=xc.device)
-        else:
-            gy = _like_memory_order(gy.to(ct), ctx.back)
-        if ctx.group is None and gscale is None and sp.channels > 1 and scale.numel() == sp.channels:
-            # per-channel scale, nothing else feeding the scale's gradient: two launches in all -- the backward
-            # kernel (dx, per-unit dscale sums and arg-max positions) and one finishing kernel that sums,
-            # converts dscale into the statistic's gradient and deposits it (None: layout not covered)
-            thr_div = _as_dtype_value(sp.int_threshold, scale.dtype)
-            dx = nat.fakequant_bwd_stats(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), stat,
-                                         scale.dtype, thr_div, scale.dtype)
-            if dx is not None:
-                return _restore(dx, ctx.back), None, None, None, None, None, None, None, None, None
-        # one pass: dx, the scale-gradient sums and the positions attaining the statistic
-        dx, ds, _, ties = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), True,
-                                            False, tie_stat=stat)
-        total_ties = None
-        if ctx.group is None and gscale is None and ds.numel() == scale.numel():
-            # dscale -> dstat -> deposit in one launch (same rounding points as the ops below)
-            dimensioned = scale.dim() > 0
-            quot_dtype = scale.dtype if dimensioned else torch.promote_types(scale.dtype, int_threshold.dtype)
-            thr_div = _as_dtype_value(sp.int_threshold, scale.dtype) if dimensioned else sp.int_threshold
-            nat.stat_tie_apply_dscale(xc.reshape(-1), stat, ds, scale.dtype, thr_div, quot_dtype, ties,
-                                      dx.reshape(-1), sp.outer, sp.channels, sp.inner, pre_op=ctx.pre_op)
-            return _restore(dx, ctx.back), None, None, None, None, None, None, None, None, None
-        if ctx.group is not None:
-            # sum the shards' partial sums, and agree on which shard deposits the statistic's gradient
-            from brevitas_amd.distributed import sync_backward
-            if gscale is not None:
-                ds = ds + gscale.reshape(-1).to(ds.dtype)
-                gscale = None
-            ds, ties, total_ties = sync_backward(ds, ties, sp.channels, ctx.group)
-        ds = _reduce_like(ds, scale)
+        dx = stats_backward(xc, scale, zp, stat, int_threshold, ctx.desc, ctx.sp, ctx.group, ctx.pre_op, ctx.back, gy,
+                            gscale)
+        return dx, None, None, None, None, None, None, None, None, None
+
+
+def stats_backward(xc, scale, zp, stat, int_threshold, desc, sp, group, pre_op, back, gy, gscale):
+    """backward of StatsFakeQuantFn (also the fallback of the C++ node, brevitas_amd/csrc/bvq_autograd.cpp) -> dx or None;
+    sp: anything with outer / channels / inner / int_threshold"""
+    ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
+    if gy is None:  # only `scale` was used downstream
+        if gscale is None:
+            return None
+        gy = torch.zeros(xc.shape, dtype=ct, device=xc.device)
+    else:
+        gy = _like_memory_order(gy.to(ct), back)
+    if group is None and gscale is None and sp.channels > 1 and scale.numel() == sp.channels:
+        # per-channel scale, nothing else feeding the scale's gradient: two launches in all -- the backward
+        # kernel (dx, per-unit dscale sums and arg-max positions) and one finishing kernel that sums,
+        # converts dscale into the statistic's gradient and deposits it (None: layout not covered)
+        thr_div = _as_dtype_value(sp.int_threshold, scale.dtype)
+        dx = nat.fakequant_bwd_stats(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), stat,
+                                     scale.dtype, thr_div, scale.dtype)
+        if dx is not None:
+            return _restore(dx, back)
+    # one pass: dx, the scale-gradient sums and the positions attaining the statistic
+    dx, ds, _, ties = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), True,
+                                        False, tie_stat=stat)
+    total_ties = None
+    if group is None and gscale is None and ds.numel() == scale.numel():
+        # dscale -> dstat -> deposit in one launch (same rounding points as the ops below)
+        dimensioned = scale.dim() > 0
+        quot_dtype = scale.dtype if dimensioned else torch.promote_types(scale.dtype, int_threshold.dtype)
+        thr_div = _as_dtype_value(sp.int_threshold, scale.dtype) if dimensioned else sp.int_threshold
+        nat.stat_tie_apply_dscale(xc.reshape(-1), stat, ds, scale.dtype, thr_div, quot_dtype, ties,
+                                  dx.reshape(-1), sp.outer, sp.channels, sp.inner, pre_op=pre_op)
+        return _restore(dx, back)
+    if group is not None:
+        # sum the shards' partial sums, and agree on which shard deposits the statistic's gradient
+        from brevitas_amd.distributed import sync_backward
         if gscale is not None:
-            ds = ds + gscale
-        # scale = thr / int_threshold  ->  dthr = dscale / int_threshold ; clamp_min_ste passes it on
-        dstat = (ds / int_threshold).to(stat.dtype).reshape(-1).contiguous()
-        nat.stat_tie_apply(nat.MATCH_ABS, xc.reshape(-1), stat, dstat, ties, dx.reshape(-1), sp.outer,
-                           sp.channels, sp.inner, mode_add=True, total_ties=total_ties, pre_op=ctx.pre_op)
-        return _restore(dx, ctx.back), None, None, None, None, None, None, None, None, None
+            ds = ds + gscale.reshape(-1).to(ds.dtype)
+            gscale = None
+        ds, ties, total_ties = sync_backward(ds, ties, sp.channels, group)
+    ds = _reduce_like(ds, scale)
+    if gscale is not None:
+        ds = ds + gscale
+    # scale = thr / int_threshold  ->  dthr = dscale / int_threshold ; clamp_min_ste passes it on
+    dstat = (ds / int_threshold).to(stat.dtype).reshape(-1).contiguous()
+    nat.stat_tie_apply(nat.MATCH_ABS, xc.reshape(-1), stat, dstat, ties, dx.reshape(-1), sp.outer,
+                       sp.channels, sp.inner, mode_add=True, total_ties=total_ties, pre_op=pre_op)
+    return _restore(dx, back)
+
+
+# ---- the weight quantizer's autograd node in C++ (brevitas_amd/csrc/bvq_autograd.cpp) ------------------------------
+# Optional host-side accelerator: one native call each way instead of the Python Function + ctypes wrappers (85 -> ~50 us
+# of host time per weight-sized step).  Built in-tree by brevitas_amd/csrc/build.py; when the module is absent the
+# Python Function above serves every call -- same kernels, same results either way.
+_FAST = None          # the loaded extension module, False after a failed attempt
+_FAST_PATH = None
+
+
+class _SpLike(NamedTuple):
+    outer: int
+    channels: int
+    inner: int
+    int_threshold: float
+
+
+def _fast_backward_fallback(xc, scale, zp, stat, int_threshold, dv, qr, shape, gy, gscale):
+    """what the C++ node cannot do itself (a gradient arriving through `scale`, an unaligned or strided gradient)"""
+    desc = nat.QuantDesc(dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], dv[7], dv[8], qr[0], qr[1], dv[9], dv[10],
+                         dv[11], dv[12], dv[13], dv[14])
+    sp = _SpLike(dv[0], dv[1], dv[2], qr[3])
+    return stats_backward(xc, scale.view(shape), zp, stat, int_threshold, desc, sp, None, dv[13], None, gy, gscale)
+
+
+def _fast_module():
+    global _FAST, _FAST_PATH
+    if _FAST is None:
+        import importlib.util
+        import os
+        _FAST = False
+        path = os.path.join(os.path.dirname(nat.LIB_PATH), '_bvq_autograd.so')
+        if config.CPP_AUTOGRAD and os.path.exists(path):
+            try:
+                spec = importlib.util.spec_from_file_location('_bvq_autograd', path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                mod.init(nat.LIB_PATH, _fast_backward_fallback)
+                _FAST, _FAST_PATH = mod, path
+            except Exception:  # noqa: BLE001  (an extension built against another torch: the Python route serves)
+                _FAST = False
+    return _FAST
+
+
+def fast_stats_fakequant(x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, pre_op):
+    """StatsFakeQuantFn through the C++ node -> (y, scale, stat), or None: not a case it covers (per-tensor scale,
+    channels_last / strided input, layouts outside the one-launch forward, no extension built, timers active)"""
+    mod = _fast_module()
+    if not mod or not x.is_cuda or sp.nhwc or sp.channels <= 1 or not x.is_contiguous() or x.dtype not in _FLOATS \
+            or not config.FUSED_PATHS:
+        return None
+    timer = nat._timer
+    if timer is not None and getattr(timer, 'enabled', True):
+        return None  # bench.py is bracketing the C-ABI calls of this step with HIP events: keep them visible
+    if len(sp.scaling_shape) > 0:
+        scale_dtype, thr_div = x.dtype, _as_dtype_value(sp.int_threshold, x.dtype)
+    else:
+        scale_dtype = torch.promote_types(x.dtype, int_threshold.dtype)
+        thr_div = sp.int_threshold
+    code, sdt = nat.dtype_code(x.dtype), nat.dtype_code(scale_dtype)
+    zp = _zero_zero_point(x.device)
+    dv = (sp.outer, sp.channels, sp.inner, code, code, sdt, nat.dtype_code(zp.dtype), 1, 0, round_mode, scalar_mode(),
+          int(clamp_ste), nat.OUT_DEQUANT, pre_op, 0)
+    thr_bwd = _as_dtype_value(sp.int_threshold, scale_dtype)
+    return mod.stats_fakequant(x, zp, int_threshold, dv, float(qmin), float(qmax), float(sp.min_val or 0.0),
+                               bool(sp.min_val), float(thr_div), float(thr_bwd), float(sp.int_threshold), sdt,
+                               list(sp.scaling_shape), nat.stream_ptr(x.device))

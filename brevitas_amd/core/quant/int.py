@@ -245,9 +245,16 @@ class RescalingIntQuant(torch.nn.Module):
             group = getattr(self, 'bvq_shard_group', None) if runtime is not None else None
             if runtime is not None:
                 runtime.bvq_running_folded = False
-            y, scale, stat = _fused.StatsFakeQuantFn.apply(
-                x, int_threshold, sp, tmpl['qmin'], tmpl['qmax'], tmpl['round_mode'], tmpl['clamp_ste'], group,
-                pre_op, runtime)
+            fast = None
+            if runtime is None and group is None:  # a weight: the autograd node in C++ when it is built and applies
+                fast = _fused.fast_stats_fakequant(x, int_threshold, sp, tmpl['qmin'], tmpl['qmax'], tmpl['round_mode'],
+                                                   tmpl['clamp_ste'], pre_op)
+            if fast is not None:
+                y, scale, stat = fast
+            else:
+                y, scale, stat = _fused.StatsFakeQuantFn.apply(
+                    x, int_threshold, sp, tmpl['qmin'], tmpl['qmax'], tmpl['round_mode'], tmpl['clamp_ste'], group,
+                    pre_op, runtime)
             if runtime is not None:
                 if runtime.bvq_running_folded:   # updated by the statistic's own finishing launch
                     runtime.first_batch = False

@@ -88,6 +88,35 @@ def build(force=False, verbose=False, defines=(), out=None):
     return lib_path
 
 
+AUTOGRAD_SO = os.path.join(PKG, '_bvq_autograd.so')
+
+
+def build_autograd(force=False, verbose=False):
+    """Compile the optional C++ autograd node (bvq_autograd.cpp: host code only, g++ against torch's headers) in-tree ->
+    brevitas_amd/_bvq_autograd.so.  The package works without it (Python Function); returns the path or None."""
+    src = os.path.join(CSRC, 'bvq_autograd.cpp')
+    import torch
+    h = hashlib.sha256()
+    with open(src, 'rb') as fh:
+        h.update(fh.read())
+    h.update(torch.__version__.encode())
+    stamp = os.path.join(ROOT, 'build', 'autograd', 'stamp')
+    if not force and os.path.exists(AUTOGRAD_SO) and os.path.exists(stamp):
+        with open(stamp) as fh:
+            if fh.read().strip() == h.hexdigest():
+                return AUTOGRAD_SO
+    from torch.utils import cpp_extension
+    bdir = os.path.join(ROOT, 'build', 'autograd')
+    os.makedirs(bdir, exist_ok=True)
+    cpp_extension.load(name='_bvq_autograd', sources=[src], build_directory=bdir, extra_cflags=['-O2', '-std=c++17'],
+                       extra_ldflags=['-ldl'], verbose=verbose, is_python_module=False)
+    built = os.path.join(bdir, '_bvq_autograd.so')
+    shutil.copyfile(built, AUTOGRAD_SO)
+    with open(stamp, 'w') as fh:
+        fh.write(h.hexdigest())
+    return AUTOGRAD_SO
+
+
 if __name__ == '__main__':
     defs = [a[2:] for a in sys.argv[1:] if a.startswith('-D')]
     outs = [a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--out=')]

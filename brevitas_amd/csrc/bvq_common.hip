@@ -42,14 +42,19 @@ int default_piece_chunks() {
 // per wave -- the no-arithmetic copy of tools/yardstick.py peaks there too.  The 16-bit kernels keep 8 KiB: with the
 // scale-gradient sums they are close to the VALU limit and the per-unit work (scale, reciprocal, two wave reductions)
 // of twice as many units costs more than the shorter units give (profiles/r02_per_tensor_pieces.txt).
-static int quant_piece_chunks(int vec) {
+static int quant_piece_chunks(int vec, int64_t row_len) {
   static int v = [] {
     const char* e = getenv("BVQ_QUANT_PIECE_CHUNKS");  // experiments only
     const int n = e ? atoi(e) : 0;
     return (n >= 1 && n <= 4096) ? n : 0;
   }();
   if (v) return v;
-  return vec == 4 ? 4 : default_piece_chunks();  // (vec 4 = float32 in 16-byte chunks)
+  if (vec == 4) return 4;  // (vec 4 = float32 in 16-byte chunks)
+  // 16-bit types: 8 KiB -- except for very long rows (a per-tensor activation), where 7 KiB pieces stream 2-3 %
+  // faster than pieces of a power of two (profiles/r02_per_tensor_pieces.txt: 495 -> 510 Gelem/s on the per-tensor
+  // headline step); a row of a few pieces (an [8192,8192] weight: two of 8 KiB) stays evenly cut
+  const int64_t quantum = (int64_t)kWave * vec;
+  return row_len >= 64 * (int64_t)default_piece_chunks() * quantum ? 7 : default_piece_chunks();
 }
 static int max_units_per_channel_quant() {
   static int v = [] {
@@ -199,7 +204,7 @@ Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, in
   t.rpu = 1;
   t.reverse = 0;
   if (row_len >= piece) {
-    if (few_rows) piece = (int64_t)quant_piece_chunks(vec) * quantum;
+    if (few_rows) piece = (int64_t)quant_piece_chunks(vec, row_len) * quantum;
     // long rows: cut them into default-sized pieces (a per-tensor quantizer is one very long row: ~10^5
     // units, whose partials the finish kernels combine in two stages), bounded by unit_cap per channel.
     if (unit_cap <= 0) unit_cap = few_rows ? max_units_per_channel_quant() : max_units_per_channel();

@@ -1,0 +1,85 @@
+"""The weight quantizer's autograd node in C++ (brevitas_amd/csrc/bvq_autograd.cpp) against the Python
+torch.autograd.Function: same kernels, so y / scale / dx must be identical bit for bit -- on the direct route and on
+every case the node hands back to Python (a gradient through `scale`, a strided gradient, only `scale` used)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _bits(t):
+    return t.detach().contiguous().view(torch.int16 if t.element_size() == 2 else torch.int32)
+
+
+def _step(q, w, g, h=None, strided=False, use_y=True):
+    w.grad = None
+    y, scale, _, _ = q(w)
+    gg = g.transpose(0, 1).contiguous().transpose(0, 1) if strided else g
+    loss = (y * gg).sum() if use_y else 0.0
+    if h is not None:
+        loss = loss + (scale.reshape(-1).float() * h).sum()
+    loss.backward()
+    return y.detach().clone(), scale.detach().clone(), w.grad.detach().clone()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16], ids=['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(64, 32, 3, 3), (128, 256), (16, 8, 1, 1)], ids=lambda s: 'x'.join(map(str, s)))
+def test_cpp_node_equals_python_function(dtype, shape, monkeypatch):
+    import brevitas_amd.quant as Q
+    from brevitas_amd.core.quant import _fused
+    assert _fused._fast_module(), 'brevitas_amd/_bvq_autograd.so is not built (python -c "import __graft_entry__ as g; g.build()")'
+    torch.manual_seed(123456)
+    w = torch.nn.Parameter((torch.randn(shape, device=DEV) * 0.05).to(dtype))
+    g = torch.randn(shape, device=DEV).to(dtype)
+    h = torch.randn(shape[0], device=DEV)
+    q = Q.Int8WeightPerChannelFloat(w).to(DEV)
+    calls = {'n': 0}
+    real = _fused.fast_stats_fakequant
+
+    def counted(*a, **k):
+        r = real(*a, **k)
+        calls['n'] += r is not None
+        return r
+    cases = [dict(), dict(h=h), dict(strided=True), dict(h=h, use_y=False)]
+    monkeypatch.setattr(_fused, 'fast_stats_fakequant', counted)
+    fast = [_step(q, w, g, **c) for c in cases]
+    assert calls['n'] == len(cases), 'the C++ node did not take these steps'
+    with torch.no_grad():
+        y_ng = q(w)[0]
+    monkeypatch.setattr(_fused, 'fast_stats_fakequant', lambda *a, **k: None)
+    slow = [_step(q, w, g, **c) for c in cases]
+    for (ya, sa, da), (yb, sb, db), c in zip(fast, slow, cases):
+        assert torch.equal(_bits(ya), _bits(yb)) and torch.equal(_bits(sa), _bits(sb)), c
+        assert torch.equal(_bits(da), _bits(db)), c
+    assert torch.equal(_bits(y_ng), _bits(slow[0][0]))
+
+
+def test_cpp_node_step_captures_into_a_hip_graph():
+    import brevitas_amd.quant as Q
+    from brevitas_amd.core.quant import _fused
+    assert _fused._fast_module()
+    torch.manual_seed(1)
+    w = torch.nn.Parameter(torch.randn(64, 32, 3, 3, device=DEV) * 0.05)
+    g = torch.randn(64, 32, 3, 3, device=DEV)
+    q = Q.Int8WeightPerChannelFloat(w).to(DEV)
+
+    def step():
+        w.grad = None
+        y = q(w)[0]
+        y.backward(g)
+        return y
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    want_y, want_dx = step().detach().clone(), w.grad.detach().clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = step()
+        dx = w.grad
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, want_y) and torch.equal(dx, want_dx)
