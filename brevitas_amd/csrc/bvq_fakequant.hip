@@ -281,11 +281,14 @@ struct ColsLane {
   }
 };
 
-// This file is compiled twice (brevitas_amd/csrc/build.py): BVQ_PART=1 holds the forward kernels and
-// entry point, BVQ_PART=2 the backward ones -- two translation units build in parallel.
+// This file is compiled several times (brevitas_amd/csrc/build.py) so that its translation units build in parallel:
+// BVQ_PART=1 holds the forward kernels and entry points, BVQ_PART=2 the backward entry points with the column-mapped
+// and finishing kernels, BVQ_PART=21 / 22 / 23 the row-mapped backward kernel for bf16 / float16 / float32-arithmetic
+// tensors (explicit instantiations of launch_bwd, the long pole of the build).
 #ifndef BVQ_PART
 #define BVQ_PART 0  // 0: everything in one translation unit
 #endif
+#define BVQ_BWD_CODE (BVQ_PART == 0 || BVQ_PART == 2 || BVQ_PART == 21 || BVQ_PART == 22 || BVQ_PART == 23)
 
 #if BVQ_PART == 0 || BVQ_PART == 1
 // ------------------------------------------------------------------------------------------------
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant
 
 #endif  // forward part
 
-#if BVQ_PART == 0 || BVQ_PART == 2
+#if BVQ_BWD_CODE
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
@@ -1420,7 +1423,7 @@ static void launch_fwd(const QuantArgs& a, int vec, bool nt, hipStream_t st) {
 
 #endif
 
-#if BVQ_PART == 0 || BVQ_PART == 2
+#if BVQ_BWD_CODE
 template <typename XT, typename CT, int MODE>
 static void launch_bwd_mode(const QuantArgs& a, int vec, bool nt, hipStream_t st) {
   constexpr int V = elem<XT>::vec;
@@ -1455,7 +1458,7 @@ static void launch_bwd_mode(const QuantArgs& a, int vec, bool nt, hipStream_t st
 }
 
 template <typename XT, typename CT>
-static void launch_bwd(const QuantArgs& a, int vec, int mode, bool nt, hipStream_t st) {
+void launch_bwd(const QuantArgs& a, int vec, int mode, bool nt, hipStream_t st) {
   switch (mode) {
     case kBwdDx:
       launch_bwd_mode<XT, CT, kBwdDx>(a, vec, nt, st);
@@ -1474,6 +1477,26 @@ static void launch_bwd(const QuantArgs& a, int vec, int mode, bool nt, hipStream
       break;
   }
 }
+
+
+// which translation unit instantiates the row-mapped backward of which dtype pair (see the top of the file)
+#define BVQ_LAUNCH_BWD(XT, CT) void launch_bwd<XT, CT>(const QuantArgs&, int, int, bool, hipStream_t)
+#if BVQ_PART == 2
+extern template BVQ_LAUNCH_BWD(float, float);
+extern template BVQ_LAUNCH_BWD(bf16_t, bf16_t);
+extern template BVQ_LAUNCH_BWD(bf16_t, float);
+extern template BVQ_LAUNCH_BWD(f16_t, f16_t);
+extern template BVQ_LAUNCH_BWD(f16_t, float);
+#elif BVQ_PART == 21
+template BVQ_LAUNCH_BWD(bf16_t, bf16_t);
+#elif BVQ_PART == 22
+template BVQ_LAUNCH_BWD(f16_t, f16_t);
+#elif BVQ_PART == 23
+template BVQ_LAUNCH_BWD(float, float);
+template BVQ_LAUNCH_BWD(bf16_t, float);
+template BVQ_LAUNCH_BWD(f16_t, float);
+#endif
+#undef BVQ_LAUNCH_BWD
 
 #endif
 
