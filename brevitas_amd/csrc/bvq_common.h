@@ -348,9 +348,30 @@ __device__ __forceinline__ Unit locate_unit(const Tiling& t) {
     u.nrows = u.channel = 0;
     return u;
   }
-  const int64_t rc = u.id / t.ppr;  // (outer_block, channel)
-  const int64_t piece = u.id - rc * t.ppr;
-  const int64_t ob = rc / t.channels;
+  // (outer_block, channel, piece) from the unit id.  A wave-uniform 64-bit division is ~100 VALU instructions on
+  // gfx9 (no scalar divide): short rows have one piece per row (no division), and ids below 2^31 -- every tensor but
+  // the very largest -- divide in 32 bits.  The two divisions were most of the ~190 VALU instructions a unit of the
+  // headline backward spent outside its hot loop (profiles/r02/pmc_final_build.md).
+  int64_t rc, piece, ob;
+#ifndef BVQ_LOCATE64
+  if (u.id < ((int64_t)1 << 31) && t.ppr < ((int64_t)1 << 31)) {
+    const uint32_t id32 = (uint32_t)u.id;
+    uint32_t rc32 = id32, piece32 = 0;
+    if (t.ppr != 1) {
+      rc32 = id32 / (uint32_t)t.ppr;
+      piece32 = id32 - rc32 * (uint32_t)t.ppr;
+    }
+    const uint32_t ob32 = rc32 / (uint32_t)t.channels;
+    rc = rc32;
+    piece = piece32;
+    ob = ob32;
+  } else
+#endif
+  {
+    rc = u.id / t.ppr;
+    piece = u.id - rc * t.ppr;
+    ob = rc / t.channels;
+  }
   u.channel = (int32_t)(rc - ob * t.channels);
   const int64_t o0 = ob * t.rpu;
   const int64_t left = t.outer - o0;
@@ -378,9 +399,15 @@ struct ChunkCursor {
     cpr = (int32_t)(u.len / vec);
     nrows = u.nrows;
     const int32_t c = cpr > 0 ? cpr : 1;
-    dq = kWave / c;
-    dr = kWave - dq * c;
-    const int32_t r0 = lane / c;  // 0 for every lane when a row has >= 64 chunks
+    int32_t r0 = 0;  // 0 for every lane when a row has >= 64 chunks
+    if (c >= kWave) {  // (wave-uniform; spares two integer divisions, ~50 VALU instructions per unit)
+      dq = 0;
+      dr = kWave;
+    } else {
+      dq = kWave / c;
+      dr = kWave - dq * c;
+      r0 = lane / c;
+    }
     chunk = lane - r0 * c;
     // rows shorter than one chunk: nothing to walk (the ragged-end code takes them)
     row = cpr > 0 ? r0 : nrows;
