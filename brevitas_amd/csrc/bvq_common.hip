@@ -213,6 +213,12 @@ Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, in
     if (row_len > piece * max_ppr) {
       piece = (row_len + max_ppr - 1) / max_ppr;
       piece = ((piece + quantum - 1) / quantum) * quantum;
+    } else if (few_rows && row_len < 16 * piece) {
+      // a row of a few pieces: cut it evenly (a float32 56x56 map is 3136 elements: 1280 + 1280 + 576 instead of
+      // 3 x 1024 + a 64-element unit)
+      int64_t n = (row_len + piece / 2) / piece;
+      if (n < 1) n = 1;
+      piece = (((row_len + n - 1) / n + quantum - 1) / quantum) * quantum;
     }
   } else {
     // short rows: one piece per row, several rows of one channel per unit, within ~8 pieces worth of
