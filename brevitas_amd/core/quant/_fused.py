@@ -548,6 +548,8 @@ def fast_stats_fakequant(x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste
     timer = nat._timer
     if timer is not None and getattr(timer, 'enabled', True):
         return None  # bench.py is bracketing the C-ABI calls of this step with HIP events: keep them visible
+    if x.device.index is not None and x.device.index != torch.cuda.current_device():
+        return None  # the node launches on the current device: the Python route switches devices around its calls
     if len(sp.scaling_shape) > 0:
         scale_dtype, thr_div = x.dtype, _as_dtype_value(sp.int_threshold, x.dtype)
     else:
