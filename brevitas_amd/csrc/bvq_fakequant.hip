@@ -469,7 +469,10 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
 template <typename T, int RM, bool NT, bool ZP0, bool FAST>
 __device__ __forceinline__ void cols_fwd_rows(const ColsQuantArgs& a, const ColsLane<T>& ln, float qmin, float qmax) {
   constexpr int VEC = elem<T>::vec;
-  constexpr int kU = 4;
+#ifndef BVQ_COLS_FWD_UNROLL
+#define BVQ_COLS_FWD_UNROLL 4  // rows in flight per lane
+#endif
+  constexpr int kU = BVQ_COLS_FWD_UNROLL;
   const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + (int64_t)ln.chunk * VEC;
   T* __restrict__ yp = reinterpret_cast<T*>(a.y) + (int64_t)ln.chunk * VEC;
   f2 r2[VEC / 2];
