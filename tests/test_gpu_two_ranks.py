@@ -45,7 +45,8 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, root)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         import brevitas_amd.quant as Q
         from bench import build_quantizer
@@ -117,6 +118,10 @@ def test_two_ranks_on_one_device_equal_the_full_batch():
         p.start()
     for p in procs:
         p.join(timeout=300)
+    for p in procs:  # a worker that is still alive is stuck: do not leave it on the GPU
+        if p.is_alive():
+            p.terminate()
+            p.join(timeout=10)
     results = [q.get(timeout=5) for _ in range(world)]
     for rank, msg in results:
         assert msg == 'ok', 'rank %d failed:\n%s' % (rank, msg)
