@@ -97,3 +97,36 @@ def test_f16_forward_and_backward_with_tiny_values(oracle, layout, zp_kind):
     dx, ds, _ = nat.fakequant_bwd(d, gd, xd, scale, zp.to(DEV), True, False)[:3]
     assert np.array_equal(to_np(dx), dx_o)
     np.testing.assert_allclose(ds.cpu().numpy().reshape(-1), np.asarray(ds_o).reshape(-1), rtol=2e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('case', [('bf16', 300001), ('f16', 300001), ('f32', 70003), ('f32', 3136 * 6), ('bf16', 8192 * 5)],
+                         ids=lambda c: '%s-%d' % c)
+def test_long_rows_piece_rules_against_the_oracle(oracle, case):
+    """per-tensor rows long enough for every piece rule of the quantizer kernels (7 KiB pieces of 16-bit rows with
+    >= 64 pieces, 4 KiB float32 pieces, evenly cut rows of a few pieces, ragged last pieces): forward codes / values
+    and dx bit-exact, the scale gradient within summation-order tolerance"""
+    from brevitas_amd import _native as nat
+    O = oracle
+    name, n = case
+    dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[name]
+    g = torch.Generator().manual_seed(123456 + n)
+    x = (torch.randn(n, generator=g) * 1.5).to(dt)
+    gr = torch.randn(n, generator=g).to(dt)
+    code = nat.dtype_code(dt)
+    scale = torch.tensor([3.0 / 127.0]).to(dt)
+    zp = torch.zeros(1)
+    od = O.make_desc(1, 1, n, code, code, code, O.F32, scale_per_channel=False, zp_per_channel=False, qmin=-127.0,
+                     qmax=127.0, round_mode=0, clamp_ste=False, pre_op=0)
+    d = ndesc(nat, od)
+    xn, _ = O.from_torch(x)
+    gn, _ = O.from_torch(gr)
+    sn, _ = O.from_torch(scale)
+    y_o, codes_o = O.fakequant_fwd(od, xn, sn, zp.numpy().astype(np.float32))
+    xd, gd, sd, zd = x.to(DEV), gr.to(DEV), scale.to(DEV), zp.to(DEV)
+    y, codes = nat.fakequant_fwd(d, xd, sd, zd, want_codes=True)
+    assert np.array_equal(to_np(y), y_o) and np.array_equal(to_np(codes), codes_o)
+    dx_o, ds_o, _ = O.fakequant_bwd(od, gn, xn, sn, zp.numpy().astype(np.float32))
+    dx, ds, _ = nat.fakequant_bwd(d, gd, xd, sd, zd, True, False)[:3]
+    assert np.array_equal(to_np(dx), dx_o)
+    np.testing.assert_allclose(ds.cpu().numpy().reshape(-1), np.asarray(ds_o).reshape(-1), rtol=2e-3, atol=1e-2)
+    assert np.array_equal(to_np(nat.fakequant_bwd(d, gd, xd, sd, zd, False, False)[0]), dx_o)  # the dx-only kernel
