@@ -110,6 +110,8 @@ class Job:
             g = torch.randn(shape, device=device, dtype=dtype)
             self.acts.append((x, g, build_quantizer(shape[1], kind == 'act_pc', device, group)))
         elif kind in ('weight_conv', 'weight_linear'):
+            if act_shape is not None:
+                raise ValueError('a weight workload has no activation to reshape')
             shape, scale, bits = ((512, 512, 3, 3), 0.02, 8) if kind == 'weight_conv' else ((8192, 8192), 0.01, 4)
             w = torch.nn.Parameter((torch.randn(shape, device=device) * scale).to(dtype))
             g = torch.randn(shape, device=device, dtype=dtype)
@@ -237,13 +239,14 @@ def cpu_baseline(shape, dtype, per_channel, budget_s=12.0):
                                                       iters, el)}
 
 
-def timed_run(job, steps, warmup, settle, world, device, timer=None, stride=8):
+def timed_run(job, steps, warmup, settle, world, device, timer=None, stride=8, on_gpu=True):
     """settle + warm-up steps untimed, then `steps` steps between barriers -> max-over-ranks seconds"""
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(settle + warmup):
         job.step()
@@ -289,7 +292,7 @@ def graph_replay_us(job, iters=200):
     return (time.perf_counter() - t0) / iters * 1e6
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -306,7 +309,116 @@ def main():
     ap.add_argument('--shard-path', action='store_true',
                     help='developer option: run the batch-sharded code path (RCCL collectives included) even with one '
                          'rank, to measure its fixed per-step overhead on a single GPU')
-    args = ap.parse_args()
+    ap.add_argument('--act-shape', default=None,
+                    help='developer option: the GLOBAL activation shape instead of the workload\'s own, e.g. 32,512,56,56 '
+                         '(what one rank of an 8-way strong split holds)')
+    ap.add_argument('--backend', default='nccl', choices=('nccl', 'gloo'),
+                    help='torch.distributed backend; gloo goes with --device cpu (a dry run of the launcher and the '
+                         'exchange protocol on CPU tensors -- never a measurement)')
+    ap.add_argument('--device', default='cuda', choices=('cuda', 'cpu'))
+    ap.add_argument('--no-n1', action='store_true',
+                    help='N > 1: skip rank 0\'s single-GPU run of the whole tensor (no speedup_vs_n1 in the line)')
+    ap.add_argument('--no-weak', action='store_true', help='N > 1: skip the weak-scaled side measurement')
+    ap.add_argument('--launch-timeout', type=float, default=900.0,
+                    help='bare --gpus N: seconds the launcher waits for its workers before it kills them')
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_workers(args, argv):
+    """`python bench.py --gpus N` with no torch.distributed environment: start the N ranks the way the driver's own
+    multi-GPU command does (python -m torch.distributed.run, one process per GPU) as a CHILD process group, pass
+    rank 0's JSON line through, exit with the workers' status.  This process has not touched the GPU (it must not:
+    a GPU-initialised process may not start other programs on the box) and never does."""
+    import signal
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)   # exactly the process group started above
+            except ProcessLookupError:
+                break
+            try:
+                proc.communicate(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        sys.stderr.write('bench.py: the %d workers did not finish within %.0f s; killed\n' % (args.gpus, args.launch_timeout))
+        return 124
+    lines = [ln for ln in out.decode(errors='replace').splitlines() if ln.startswith('{') and '"metric"' in ln]
+    if proc.returncode != 0:
+        sys.stderr.write('bench.py: torch.distributed.run exited with status %d\n' % proc.returncode)
+        return proc.returncode or 1
+    if len(lines) != 1:
+        sys.stderr.write('bench.py: expected one JSON line from rank 0, got %d\n' % len(lines))
+        return 1
+    sys.stdout.write(lines[0] + '\n')
+    sys.stdout.flush()
+    return 0
+
+
+class Measurement:
+    """one timed job: what the report needs of it once its tensors are freed"""
+
+    def __init__(self, job, elapsed, steps, world, timer=None):
+        self.elapsed, self.steps = elapsed, steps
+        self.ms_per_step = elapsed / steps * 1e3
+        self.n_elem, self.n_act, self.elsize = job.n_elem, job.n_act, job.elsize
+        self.bytes_per_elem = job.bytes_per_elem
+        self.shapes = [list(t[0].shape) for t in job.acts + job.weights]
+        self.bwd_elems = job.acts[0][0].numel() if job.acts else job.weights[0][0].numel()
+        # weights are replicated: every rank quantizes its own copy, counted once per rank (that is the work done)
+        self.value = job.n_elem * world * steps / elapsed / 1e9
+        self.calls = {}
+        if timer is not None:
+            b = job.elsize
+            for key, name, passes in (('statistic', 'bvq_stats', 1), ('forward', 'bvq_fakequant_fwd', 2),
+                                      ('statistic+forward', 'bvq_stats_fakequant_fwd', 3),
+                                      ('backward', 'bvq_fakequant_bwd', 3)):
+                ms = timer.mean_ms(name)
+                if ms:
+                    self.calls[key] = {'ms': round(ms, 4),
+                                       'algorithmic_GBps': round(passes * b * self.bwd_elems / (ms * 1e-3) / 1e9, 1)}
+            self.bwd_ms = timer.mean_ms('bvq_fakequant_bwd')
+        else:
+            self.bwd_ms = None
+
+    def brief(self, scaling, **extra):
+        d = {'value': round(self.value, 3), 'unit': 'Gelem/s', 'ms_per_step': round(self.ms_per_step, 4),
+             'scaling': scaling, 'tensors_per_gpu': self.shapes}
+        d.update(extra)
+        return d
+
+
+def library_digest():
+    """digest of the sources the loaded libbvq.so was built from (brevitas_amd/csrc/build.py's stamp) or None"""
+    try:
+        from brevitas_amd.csrc import build as bvq_build
+        return bvq_build.source_digest()
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # bare `python bench.py --gpus N`: this process only starts the N ranks and relays rank 0's line
+        sys.exit(launch_workers(args, argv))
 
     # stdout carries exactly ONE line, the JSON result: everything else this process or its libraries print
     # (RCCL's version banner goes to stdout) is sent to stderr until then
@@ -318,130 +430,181 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     kind, dtype, descr = WORKLOADS[args.workload]
+    on_gpu = args.device == 'cuda'
+    full_shape = tuple(int(v) for v in args.act_shape.split(',')) if args.act_shape else None
     # The CPU baseline runs FIRST, before this process touches the GPU: it may have to (re)build the
     # oracle with `make`, and a GPU-initialised process must not spawn other programs on the box.
     baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and kind in ('act_pc', 'act_pt'):
+    if rank == 0 and world == 1 and on_gpu and not args.no_cpu_baseline and kind in ('act_pc', 'act_pt'):
         baseline = cpu_baseline(ACT_SHAPE, dtype, kind == 'act_pc')
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
-                         % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a ROCm device (the product path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+        raise SystemExit('bench.py --gpus %d found WORLD_SIZE=%d in its environment' % (args.gpus, world))
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs a ROCm device (the product path has no CPU fallback for device tensors)')
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
+    else:
+        if args.backend != 'gloo' and (world > 1 or args.shard_path):
+            raise SystemExit('--device cpu goes with --backend gloo')
+        device = torch.device('cpu')
+        if full_shape is None:
+            raise SystemExit('--device cpu is a dry run of the launcher / exchange protocol: give a small --act-shape')
     group = None
+    rccl_ranks = 1
     if world > 1 or args.shard_path:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        kw = {'device_id': device} if on_gpu else {}
         if world == 1:
-            os.environ.setdefault('MASTER_PORT', '29531')
-            dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
+            os.environ.setdefault('MASTER_PORT', str(free_port()))
+            dist.init_process_group(args.backend, rank=0, world_size=1, timeout=datetime.timedelta(seconds=600), **kw)
         else:
-            dist.init_process_group('nccl', device_id=device)
+            dist.init_process_group(args.backend, timeout=datetime.timedelta(seconds=600), **kw)
         group = dist.group.WORLD
+        # the number of ranks the collective library really joined: an all-reduce of ones
+        ones = torch.ones(1, device=device, dtype=torch.float32)
+        dist.all_reduce(ones, group=group)
+        rccl_ranks = int(ones.item())
 
-    from brevitas_amd import _native as nat
-    job = Job(kind, dtype, device, group, rank)
-    timer = KernelTimer('bvq_fakequant_bwd', 'bvq_fakequant_fwd', 'bvq_stats', 'bvq_stats_fakequant_fwd')
-    nat.set_kernel_timer(timer)
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def free():
+        if on_gpu:
+            torch.cuda.empty_cache()
+
+    timer = None
+    if on_gpu:
+        from brevitas_amd import _native as nat
+        timer = KernelTimer('bvq_fakequant_bwd', 'bvq_fakequant_fwd', 'bvq_stats', 'bvq_stats_fakequant_fwd')
     settle_target = SETTLE_STEPS if args.settle_steps is None else args.settle_steps
     settle = 0 if args.no_settle else max(0, settle_target - args.warmup)
-    elapsed = timed_run(job, args.steps, args.warmup, settle, world, device, timer, args.timer_stride)
-    nat.set_kernel_timer(None)
+    has_act = kind in ('act_pc', 'act_pt', 'qconv', 'qlinear')
+    # the GLOBAL activation of the workload: the named tensor itself, or (config 4) batch 1024
+    base = {'qconv': (1024, 1024, 14, 14), 'qlinear': (8192, 8192)}.get(kind, ACT_SHAPE)
+    if not has_act:
+        base = None
+    elif full_shape is not None:
+        base = full_shape
 
+    # ---- N > 1: rank 0 alone on the whole tensor first (the N = 1 figure of the same run, same box) ---------------
+    n1 = None
+    if world > 1 and has_act and not args.no_n1:
+        if rank == 0:
+            j = Job(kind, dtype, device, None, 0, act_shape=base)
+            e = timed_run(j, args.steps, args.warmup, settle, 1, device, None, on_gpu=on_gpu)
+            n1 = Measurement(j, e, args.steps, 1)
+            del j
+            free()
+        sync()
+
+    # ---- the judged measurement ------------------------------------------------------------------------------------
+    # N > 1: STRONG scaling (north_star): the global tensor cut into 1/N of its rows per rank.  N = 1: the
+    # whole tensor.  Workloads without an activation (weights) are replicas: every rank quantizes its own copy.
+    scaling = 'strong' if has_act else 'weak'
+    if has_act and world > 1:
+        rows = base[0] // world
+        if rows < 1:
+            raise SystemExit('%d ranks for a batch of %d' % (world, base[0]))
+        shard_shape = (rows,) + tuple(base[1:])
+    else:
+        shard_shape = base
+    if timer is not None:
+        nat.set_kernel_timer(timer)
+    job = Job(kind, dtype, device, group, rank, act_shape=shard_shape)
+    elapsed = timed_run(job, args.steps, args.warmup, settle, world, device, timer, args.timer_stride, on_gpu=on_gpu)
+    if timer is not None:
+        nat.set_kernel_timer(None)
+    main_m = Measurement(job, elapsed, args.steps, world, timer)
     replay_us = None
-    if world == 1 and kind in ('weight_conv', 'weight_linear'):
+    if world == 1 and on_gpu and kind in ('weight_conv', 'weight_linear'):
         replay_us = graph_replay_us(job)
-
-    # what the report needs of the weak-scaled job (its tensors are freed before the strong-scaled run)
-    class Sizes:
-        n_elem, n_act, elsize, bytes_per_elem = job.n_elem, job.n_act, job.elsize, job.bytes_per_elem
-        shapes = [list(t[0].shape) for t in job.acts + job.weights]
-        bwd_elems = job.acts[0][0].numel() if job.acts else job.weights[0][0].numel()
-        act_shape = tuple(job.acts[0][0].shape) if job.acts else None
     del job
-    torch.cuda.empty_cache()
+    free()
 
-    # strong scaling: the GLOBAL activation of the workload cut into 1/world of its rows per rank
-    strong = None
-    if world > 1 and Sizes.act_shape is not None:
-        full = Sizes.act_shape
-        # the global batch of the workload: the named activation itself, or (config 4) batch 1024
-        rows = {'qconv': 1024}.get(kind, full[0]) // world
-        if rows >= 1:
-            sjob = Job(kind, dtype, device, group, rank, act_shape=(rows,) + full[1:])
-            s_el = timed_run(sjob, args.steps, args.warmup, 0, world, device)
-            # activation rows are split over the ranks; replicated weights are quantized by every rank
-            s_elems = sjob.n_act * world + (sjob.n_elem - sjob.n_act) * world
-            strong = {'value': round(s_elems * args.steps / s_el / 1e9, 3), 'unit': 'Gelem/s',
-                      'ms_per_step': round(s_el / args.steps * 1e3, 4), 'scaling': 'strong',
-                      'global_activation': [rows * world] + list(full[1:]), 'rows_per_gpu': rows}
-            del sjob
-    job = Sizes
+    # ---- N > 1: the weak-scaled side measurement (every rank holds the whole named tensor) --------------------------
+    weak = None
+    if world > 1 and has_act and not args.no_weak:
+        wshape = base if kind != 'qconv' else (base[0] // 8,) + tuple(base[1:])   # config 4: 128 per GPU
+        j = Job(kind, dtype, device, group, rank, act_shape=wshape)
+        e = timed_run(j, args.steps, args.warmup, 0, world, device, None, on_gpu=on_gpu)
+        weak = Measurement(j, e, args.steps, world)
+        del j
+        free()
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        # weights are replicated: every rank quantizes its own copy, counted once per rank (that is the work done)
-        value = job.n_elem * world * args.steps / elapsed / 1e9
-        b = job.elsize
-        headline = kind == 'act_pc'
+        m = main_m
+        b = m.elsize
+        headline = kind == 'act_pc' and (base == ACT_SHAPE)
         # algorithmic bytes of the backward kernel per launch: read g + read x + write dx
-        bwd_elems = job.bwd_elems
-        bwd_bytes = 3 * b * bwd_elems
-        bwd_ms = timer.mean_ms('bvq_fakequant_bwd')
-        achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
+        bwd_bytes = 3 * b * m.bwd_elems
+        achieved = bwd_bytes / (m.bwd_ms * 1e-3) / 1e9 if m.bwd_ms else None
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):
+        if on_gpu and world == 1 and os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
-            traffic = tj.get(args.workload, {}).get('bvq_fakequant_bwd')
-            if traffic is not None:
-                traffic_src = 'profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier ' \
-                              'run of this command (%s), not measured by this run' % tj.get('_source', 'see profiles/README.md')
+            digest = library_digest()
+            if tj.get('_source_digest') is not None and tj.get('_source_digest') == digest:
+                traffic = tj.get(args.workload, {}).get('bvq_fakequant_bwd')
+                if traffic is not None:
+                    traffic_src = 'profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier ' \
+                                  'run of this command on the same library sources (digest %s; %s), not measured by ' \
+                                  'this run' % (digest[:12], tj.get('_source', 'see profiles/README.md'))
+            else:
+                traffic_src = 'null: profiles/traffic.json was collected on other library sources (digest %s, this ' \
+                              'library %s)' % (str(tj.get('_source_digest'))[:12], str(digest)[:12])
         dt_name = str(dtype).replace('torch.', '').replace('bfloat16', 'bf16').replace('float32', 'f32')
         metric = 'Gelem/s fused int8 fake-quant fwd+bwd, per-channel, [256,512,56,56]' if headline else \
             'Gelem/s fake-quant fwd+bwd, ' + args.workload
+        if world > 1 and has_act:
+            par = ('dp%d, strong scaling: the global %s activation batch-sharded into %d rows per rank over %d %s ranks, '
+                   'all-reduce(MAX) of the statistic + all-gather of the scale-gradient sums; weights replicated'
+                   % (world, list(base), shard_shape[0], world, 'RCCL' if args.backend == 'nccl' else args.backend))
+        elif world > 1:
+            par = 'replicas only: %d ranks each quantize their own copy of the weight (no exchange)' % world
+        else:
+            par = 'single GPU'
         out = {
             'metric': metric,
-            'value': round(value, 3), 'unit': 'Gelem/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'settle_steps': settle, 'ms_per_step': round(ms_per_step, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dt_name,
-            'data': 'synthetic',
+            'value': round(m.value, 3), 'unit': 'Gelem/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'settle_steps': settle, 'ms_per_step': round(m.ms_per_step, 4),
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': dt_name,
+            'data': 'synthetic' if on_gpu else 'synthetic; DRY RUN on CPU tensors over %s (launcher / exchange-protocol '
+                                               'check through the pure-torch CPU route: not a measurement)' % args.backend,
             'config': {'workload': descr, 'name': args.workload,
-                       'tensors_per_gpu': job.shapes,
+                       'global_activation': list(base) if has_act else None,
+                       'tensors_per_gpu': m.shapes,
                        'quantizer': 'RescalingIntQuant(IntQuant, RuntimeStatsScaling(AbsMax) / StatsFromParameterScaling'
                                     '(AbsMax), IntScaling, ZeroZeroPoint, BitWidthConst), training mode',
-                       'parallelism': ('dp%d: activations batch-sharded over %d RCCL ranks, all-reduce(MAX) of the '
-                                       'statistic + all-gather of the scale-gradient sums; weights replicated'
-                                       % (world, world)) if world > 1 else 'single GPU',
-                       'rccl_ranks': world,
-                       'algorithmic_bytes_per_elem': job.bytes_per_elem},
-            'hbm_frac_whole_step': round(job.bytes_per_elem * job.n_elem / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       'parallelism': par,
+                       'rccl_ranks': rccl_ranks,
+                       'algorithmic_bytes_per_elem': m.bytes_per_elem},
+            'hbm_frac_whole_step': round(m.bytes_per_elem * m.n_elem * world / (m.ms_per_step * 1e-3) / 1e9
+                                         / (HBM_PEAK_GBS * world), 4),
             'roofline': {'kernel': 'fakequant_bwd_kernel (bvq_fakequant_bwd)', 'bound': 'hbm',
                          'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': bwd_bytes,
-                         'avg_launch_ms': round(bwd_ms, 4) if bwd_ms else None},
+                         'avg_launch_ms': round(m.bwd_ms, 4) if m.bwd_ms else None},
         }
-        if strong is not None:
-            out['strong'] = strong
+        if n1 is not None:
+            out['n1'] = n1.brief('single GPU, rank 0 alone on the whole tensor, same run')
+            out['speedup_vs_n1'] = round(m.value / n1.value, 3)
+        if weak is not None:
+            out['weak'] = weak.brief('weak')
         if replay_us is not None:
-            out['us_per_step_eager'] = round(ms_per_step * 1e3, 2)
+            out['us_per_step_eager'] = round(m.ms_per_step * 1e3, 2)
             out['us_per_step_graph_replay'] = round(replay_us, 2)
         # the streaming calls of the step, same method (each bracket includes its launch-bound helpers); the
         # one-launch forward (statistic + quantizer) moves the statistic's read through the Infinity Cache
-        calls = {}
-        n0 = bwd_elems
-        for key, name, passes in (('statistic', 'bvq_stats', 1), ('forward', 'bvq_fakequant_fwd', 2),
-                                  ('statistic+forward', 'bvq_stats_fakequant_fwd', 3),
-                                  ('backward', 'bvq_fakequant_bwd', 3)):
-            ms = timer.mean_ms(name)
-            if ms:
-                calls[key] = {'ms': round(ms, 4), 'algorithmic_GBps': round(passes * b * n0 / (ms * 1e-3) / 1e9, 1)}
-        out['calls'] = calls
+        out['calls'] = m.calls
         if baseline is not None:
             out['cpu_baseline'] = baseline
         sys.stdout.flush()

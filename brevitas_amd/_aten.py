@@ -115,6 +115,64 @@ def min_max(x, dim):
     return torch.max(x, dim=dim)[0], torch.min(x, dim=dim)[0]
 
 
+class _ShardedExtremum(torch.autograd.Function):
+    """max |x| / max x / min x of a BATCH-SHARDED CPU tensor (brevitas_amd.distributed over gloo): the device route's
+    protocol on torch ops -- all-reduce(MAX) of the float32 statistic forward; backward the summed gradient goes where
+    the single-process run on the concatenated batch puts it (first attaining element of the lowest rank along a
+    reduced dim, evenly over the ties of all shards for a whole-tensor reduction)."""
+
+    @staticmethod
+    def forward(ctx, x, dim, group, kind):
+        import torch.distributed as dist
+        key = torch.abs(x) if kind == 'abs' else (x if kind == 'max' else -x)
+        rows = key.reshape(1, -1) if dim is None else key.movedim(dim, -1).reshape(-1, key.shape[dim])
+        local = rows.max(dim=1).values.float()
+        dist.all_reduce(local, op=dist.ReduceOp.MAX, group=group)
+        stat_key = local.to(x.dtype)
+        ctx.save_for_backward(x, stat_key)
+        ctx.args = (dim, group, kind)
+        stat = stat_key if kind != 'min' else -stat_key
+        return stat.reshape(()) if dim is None else stat.reshape([s for i, s in enumerate(x.shape) if i != dim % x.dim()])
+
+    @staticmethod
+    def backward(ctx, gstat):
+        from .distributed import sync_backward
+        x, stat_key = ctx.saved_tensors
+        dim, group, kind = ctx.args
+        key = torch.abs(x) if kind == 'abs' else (x if kind == 'max' else -x)
+        moved = key.reshape(1, -1) if dim is None else key.movedim(dim, -1)
+        rows = moved.reshape(-1, moved.shape[-1])
+        hit = rows == stat_key.reshape(-1, 1)
+        ch = rows.shape[0]
+        g32 = gstat.reshape(-1).float()
+        if dim is None:
+            info = hit.sum().reshape(1).to(torch.int64)
+            gsum, _, total = sync_backward(g32, info, 1, group)
+            drows = torch.where(hit, (gsum / total.to(gsum.dtype)).to(x.dtype), torch.zeros((), dtype=x.dtype))
+        else:
+            first = torch.where(hit.any(dim=1), hit.to(torch.int8).argmax(dim=1), torch.full((ch,), -1, dtype=torch.int64))
+            gsum, info, _ = sync_backward(g32, first, ch, group, first_only=True)
+            drows = torch.zeros_like(rows)
+            own = info >= 0
+            drows[own.nonzero().reshape(-1), info[own]] = gsum.to(x.dtype)[own]
+        d = drows.reshape(moved.shape)
+        d = d.reshape(x.shape) if dim is None else d.movedim(-1, dim)
+        if kind == 'abs':
+            d = d * torch.sgn(x)
+        elif kind == 'min':
+            pass  # d(min x)/dx = +1 at the arg-min: the key's sign and the statistic's cancel
+        return d, None, None, None
+
+
+def sharded_abs_max(x, dim, group):
+    return _ShardedExtremum.apply(x, dim, group, 'abs')
+
+
+def sharded_min_max(x, dim, group):
+    """-> (max, min)"""
+    return _ShardedExtremum.apply(x, dim, group, 'max'), _ShardedExtremum.apply(x, dim, group, 'min')
+
+
 def abs_percentile(x, q, dim):
     return _kth(x.abs(), _kth_rank_high(q, _along(x, dim)), dim)
 

@@ -17,21 +17,25 @@ from brevitas_amd import _native as nat
 from brevitas_amd.core._state import TolerantLoad
 
 
-def _on_cpu(x: Tensor, group=None) -> bool:
+def _on_cpu(x: Tensor, group=None, sharded_ok=False) -> bool:
     """CPU tensors take the pure-torch route (brevitas_amd._aten: the reference's own op composition)"""
     if x.is_cuda:
         return False
-    if group is not None:
-        raise NotImplementedError('batch-sharded statistics run on device tensors only')
+    if group is not None and not sharded_ok:
+        raise NotImplementedError('this batch-sharded statistic runs on device tensors only')
     return True
 
 
 def _abs_max(x: Tensor, dim, group=None) -> Tensor:
-    return _aten.abs_max(x, dim) if _on_cpu(x, group) else _AbsMaxFn.apply(x, dim, group)
+    if _on_cpu(x, group, sharded_ok=True):
+        return _aten.abs_max(x, dim) if group is None else _aten.sharded_abs_max(x, dim, group)
+    return _AbsMaxFn.apply(x, dim, group)
 
 
 def _min_max(x: Tensor, dim, group=None):
-    return _aten.min_max(x, dim) if _on_cpu(x, group) else _MinMaxFn.apply(x, dim, group)
+    if _on_cpu(x, group, sharded_ok=True):
+        return _aten.min_max(x, dim) if group is None else _aten.sharded_min_max(x, dim, group)
+    return _MinMaxFn.apply(x, dim, group)
 
 
 def _as_rows(x: Tensor, dim: Optional[int]):

@@ -53,6 +53,18 @@ def _digest():
     return h.hexdigest()
 
 
+def source_digest():
+    """digest of the sources + flags brevitas_amd/libbvq.so was built from, or None when the library on disk is not the
+    build of the sources on disk (bench.py stamps its tracked PMC traffic figures with it)"""
+    stamp = os.path.join(OBJ_DIR, 'stamp')
+    dig = _digest()
+    if os.path.exists(LIB) and os.path.exists(stamp):
+        with open(stamp) as fh:
+            if fh.read().strip() == dig:
+                return dig
+    return None
+
+
 def build(force=False, verbose=False, defines=(), out=None):
     """defines/out: developer experiments only (tools/microbench.py --lib): extra -D flags, other output"""
     lib_path = out or LIB

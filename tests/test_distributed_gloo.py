@@ -9,21 +9,13 @@ Property checked: batch-sharded == single process on the concatenated batch --
   channel's deposit.
 """
 import os
-import socket
 
 import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
-
-def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+from mp_util import init_gloo, run_ranks
 
 
 def _first_positions(x_shard, stat, c, inner):
@@ -44,9 +36,7 @@ def _worker(rank, world, port, per_channel, q):
     sys.path.insert(0, root)
     import oracle as O
     from brevitas_amd.distributed import sync_backward, sync_stat_max
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    init_gloo(rank, world, port)
     try:
         g = torch.Generator().manual_seed(123456)
         n, c, h, w = 4, 6, 5, 4
@@ -111,16 +101,4 @@ def _worker(rank, world, port, per_channel, q):
 
 @pytest.mark.parametrize('per_channel', [True, False], ids=['per_channel', 'per_tensor'])
 def test_sharded_equals_full_batch(oracle, per_channel):
-    world = 2
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, per_channel, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=180)
-    results = [q.get(timeout=5) for _ in range(world)]
-    for rank, msg in results:
-        assert msg == 'ok', 'rank %d failed:\n%s' % (rank, msg)
-    assert all(p.exitcode == 0 for p in procs)
+    run_ranks(_worker, 2, per_channel, timeout=180)

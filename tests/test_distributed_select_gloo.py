@@ -10,23 +10,15 @@ and an empty shard; and exactly one shard -- the first in batch order that holds
 gradient deposit."""
 import math
 import os
-import socket
 
 import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
+
+from mp_util import init_gloo, run_ranks
 
 KBITS = 11
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _keys(x, abs_key):
@@ -115,9 +107,7 @@ def _worker(rank, world, port, q):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     from brevitas_amd.distributed import sharded_kth_value, sync_backward
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    init_gloo(rank, world, port)
     try:
         g = torch.Generator().manual_seed(123456)
         full = torch.randn(1000, generator=g)
@@ -162,16 +152,4 @@ def _worker(rank, world, port, q):
 
 
 def test_sharded_select_equals_kthvalue_of_concatenation():
-    world = 2
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=240)
-    results = [q.get(timeout=5) for _ in range(world)]
-    for rank, msg in results:
-        assert msg == 'ok', 'rank %d failed:\n%s' % (rank, msg)
-    assert all(p.exitcode == 0 for p in procs)
+    run_ranks(_worker, 2, timeout=240)
