@@ -40,7 +40,10 @@ EXPORTS = (
     'bvq_fakequant_bwd_workspace_bytes', 'bvq_fakequant_bwd_stats_workspace_bytes', 'bvq_fakequant_bwd_stats', 'bvq_fakequant_bwd',
     'bvq_learned_scale', 'bvq_fakequant_bwd_learned', 'bvq_variant_fwd', 'bvq_variant_bwd_workspace_bytes', 'bvq_variant_bwd',
     'bvq_fakequant_fwd_bounds', 'bvq_fakequant_bwd_bounds', 'bvq_histc', 'bvq_absmax_scale_running', 'bvq_selftest_div_f16r',
-    'bvq_kthw_plan', 'bvq_kthw_begin', 'bvq_kthw_hist', 'bvq_kthw_pick', 'bvq_kthw_finish')
+    'bvq_kthw_plan', 'bvq_kthw_begin', 'bvq_kthw_hist', 'bvq_kthw_pick', 'bvq_kthw_finish',
+    'bvq_absmax_onepass_supported', 'bvq_absmax_scale_onepass', 'bvq_fakequant_bwd_stats_onepass_supported',
+    'bvq_fakequant_bwd_stats_onepass', 'bvq_scale_from_stat_running', 'bvq_fakequant_bwd_shard',
+    'bvq_shard_unpack_deposit')
 
 
 class QuantDesc(ctypes.Structure):
@@ -97,10 +100,17 @@ def _load(path=None, strict=True):
         'bvq_fakequant_bwd_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
         'bvq_fakequant_bwd_stats_workspace_bytes': (i64, [ctypes.POINTER(QuantDesc)]),
         'bvq_fakequant_bwd_stats': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, i32, dbl, i32, vp, i64, vp]),
+        'bvq_fakequant_bwd_stats_onepass_supported': (i32, [ctypes.POINTER(QuantDesc)]),
+        'bvq_fakequant_bwd_stats_onepass': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, i32, dbl, i32, vp, i64, vp, i64, vp]),
         'bvq_absmax_scale': (i32, [i32, i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
         'bvq_absmax_scale_running': (i32, [i32, i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, i32, vp, dbl, i32, vp, i64, vp]),
+        'bvq_absmax_onepass_supported': (i32, [i32, vp, i64, i64, i64]),
+        'bvq_absmax_scale_onepass': (i32, [i32, i32, vp, i64, i64, i64, i32, vp, dbl, i32, dbl, i32, vp, i32, vp, dbl, i32, vp, i64, vp]),
         'bvq_running_stats_update': (i32, [i32, vp, i32, vp, i64, dbl, i32, vp]),
         'bvq_scale_from_stat': (i32, [vp, i64, i32, vp, dbl, i32, dbl, i32, vp, vp]),
+        'bvq_scale_from_stat_running': (i32, [vp, i64, i32, vp, dbl, i32, dbl, i32, vp, i32, vp, dbl, i32, vp]),
+        'bvq_fakequant_bwd_shard': (i32, [ctypes.POINTER(QuantDesc), vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp]),
+        'bvq_shard_unpack_deposit': (i32, [i32, vp, vp, vp, i32, i64, i32, vp, i64, i32, dbl, i32, i32, vp, vp]),
         'bvq_shard_pack': (i32, [vp, vp, i64, i32, i32, vp, vp]),
         'bvq_shard_unpack': (i32, [vp, i32, i64, i32, i32, vp, vp, vp, vp]),
         'bvq_abs_moments_workspace_bytes': (i64, [i32, i64, i64, i64]),
@@ -228,6 +238,30 @@ def set_kernel_timer(timer):
     _timer = timer
 
 
+# ---- arrival buffers of the one-launch kernels --------------------------------------------------------------------
+# include/bvq.h, bvq_absmax_scale_onepass: per-channel key / counter words that are zero when a launch starts and that
+# the launch hands back as zeros.  One buffer per (device, stream), zero-filled once when it is allocated; launches
+# on one stream are ordered, so they can share it.  Not allocated while a stream is capturing (the capture would
+# own the memory): those calls take the two-launch route.
+ARRIVE_WORDS = 1 << 16
+_arrive = {}
+ONEPASS = os.environ.get('BREVITAS_AMD_ONEPASS', '1') != '0'
+ONEPASS_BWD = os.environ.get('BREVITAS_AMD_ONEPASS_BWD', '1') != '0'   # developer A/B switch of the backward alone
+
+
+def arrival_buffer(dev, stream, words):
+    """-> int32 tensor of >= words zeros for this device and stream, or None (capturing / switched off)"""
+    if not ONEPASS or words > ARRIVE_WORDS:
+        return None
+    key = (dev.index, stream)
+    buf = _arrive.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        buf = _arrive[key] = torch.zeros(ARRIVE_WORDS, dtype=torch.int32, device=dev)
+    return buf
+
+
 # ---- thin wrappers: allocate outputs with torch, pass raw pointers --------------------------------
 
 def unary(op, x):
@@ -301,6 +335,19 @@ def stats(kind, x, outer, channels, inner, out_f32=False, pre_op=PRE_NONE):
     dt = dtype_code(x.dtype)
     nout = channels * (2 if kind == STAT_MINMAX else 1)
     out = torch.empty(nout, dtype=torch.float32 if out_f32 else x.dtype, device=dev)
+    if kind == STAT_ABSMAX and channels > 1 and lib.bvq_absmax_onepass_supported(dt, ptr(x), outer, channels, inner):
+        with _DeviceGuard(dev):
+            st = stream_ptr(dev)
+            arrive = arrival_buffer(dev, st, 2 * channels)
+            if arrive is not None:
+                if _timer is not None:
+                    _timer.before('bvq_stats')
+                check(lib.bvq_absmax_scale_onepass(pre_op, dt, ptr(x), outer, channels, inner, dtype_code(out.dtype),
+                                                   ptr(out), 0.0, 0, 1.0, 0, None, 0, None, 0.0, 0, ptr(arrive),
+                                                   arrive.numel(), st), 'bvq_absmax_scale_onepass')
+                if _timer is not None:
+                    _timer.after('bvq_stats')
+                return out
     wsb = lib.bvq_stats_workspace_bytes(kind, dt, outer, channels, inner)
     if wsb < 0:
         raise BvqError('bvq_stats_workspace_bytes: bad arguments')
@@ -385,6 +432,22 @@ def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype,
     dt = dtype_code(x.dtype)
     stat = torch.empty(channels, dtype=x.dtype, device=dev)
     scale = torch.empty(channels, dtype=scale_dtype, device=dev)
+    if channels > 1 and lib.bvq_absmax_onepass_supported(dt, ptr(x), outer, channels, inner):
+        # one launch: the statistic kernel's last-arriving wave per channel finishes it
+        with _DeviceGuard(dev):
+            st = stream_ptr(dev)
+            arrive = arrival_buffer(dev, st, 2 * channels)
+            if arrive is not None:
+                if _timer is not None:
+                    _timer.before('bvq_stats')
+                check(lib.bvq_absmax_scale_onepass(
+                    pre_op, dt, ptr(x), outer, channels, inner, dt, ptr(stat), float(min_val or 0.0),
+                    int(bool(min_val)), float(int_threshold), dtype_code(scale_dtype), ptr(scale),
+                    dtype_code(running.dtype) if running is not None else 0, ptr(running), float(momentum),
+                    int(first_batch), ptr(arrive), arrive.numel(), st), 'bvq_absmax_scale_onepass')
+                if _timer is not None:
+                    _timer.after('bvq_stats')
+                return stat, scale
     wsb = lib.bvq_stats_workspace_bytes(STAT_ABSMAX, dt, outer, channels, inner)
     ws = torch.empty(max(int(wsb), 8), dtype=torch.uint8, device=dev)
     with _DeviceGuard(dev):
@@ -445,18 +508,64 @@ KTH_EXPLICIT, KTH_HIGH, KTH_LOW = 0, 1, 2
 _KBINS = 2048
 
 
-def scale_from_stat(stat32, stat_dtype, min_val, int_threshold, scale_dtype):
-    """all-reduced float32 statistic [channels] -> (stat in stat_dtype, scale in scale_dtype), one launch"""
-    dev = require_device(stat32)
+def scale_from_stat(stat32, stat_dtype, min_val, int_threshold, scale_dtype, running=None, momentum=0.0,
+                    first_batch=False):
+    """all-reduced float32 statistic [channels] -> (stat in stat_dtype, scale in scale_dtype), one launch; running
+    (contiguous [channels] buffer): _RuntimeStats' running average updated in the same launch"""
+    dev = require_device(stat32, running)
     assert stat32.dtype == torch.float32 and stat32.is_contiguous()
     n = stat32.numel()
     stat = torch.empty(n, dtype=stat_dtype, device=dev)
     scale = torch.empty(n, dtype=scale_dtype, device=dev)
     with _DeviceGuard(dev):
-        check(lib.bvq_scale_from_stat(ptr(stat32), n, dtype_code(stat_dtype), ptr(stat), float(min_val or 0.0),
-                                      int(bool(min_val)), float(int_threshold), dtype_code(scale_dtype), ptr(scale),
-                                      stream_ptr(dev)), 'bvq_scale_from_stat')
+        check(lib.bvq_scale_from_stat_running(
+            ptr(stat32), n, dtype_code(stat_dtype), ptr(stat), float(min_val or 0.0), int(bool(min_val)),
+            float(int_threshold), dtype_code(scale_dtype), ptr(scale),
+            dtype_code(running.dtype) if running is not None else 0, ptr(running), float(momentum), int(first_batch),
+            stream_ptr(dev)), 'bvq_scale_from_stat_running')
     return stat, scale
+
+
+def fakequant_bwd_shard(desc, g, x, scale, zp, stat, rank):
+    """backward of the stats-scaled per-channel graph on ONE BATCH SHARD: -> (dx without the deposit, this shard's
+    float64 [2 * channels] all-gather message, first arg-max position per channel), or None if the layout is not
+    covered (include/bvq.h, bvq_fakequant_bwd_shard)"""
+    dev = require_device(g, x, scale, zp, stat)
+    wsb = int(lib.bvq_fakequant_bwd_stats_workspace_bytes(ctypes.byref(desc)))
+    if wsb <= 0 or (x.data_ptr() | g.data_ptr()) & 15:
+        return None
+    ch = int(desc.channels)
+    dx = torch.empty_like(x)
+    msg = torch.empty(2 * ch, dtype=torch.float64, device=dev)
+    pos = torch.empty(ch, dtype=torch.int64, device=dev)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    stat = stat.to(x.dtype).contiguous()
+    with _DeviceGuard(dev):
+        st = stream_ptr(dev)
+        arrive = arrival_buffer(dev, st, ch) if ONEPASS_BWD else None
+        if _timer is not None:
+            _timer.before('bvq_fakequant_bwd')
+        check(lib.bvq_fakequant_bwd_shard(ctypes.byref(desc), ptr(g), ptr(x), ptr(scale), ptr(zp), ptr(stat), ptr(dx),
+                                          ptr(msg), ptr(pos), int(rank), ptr(ws), wsb, ptr(arrive),
+                                          arrive.numel() if arrive is not None else 0, st), 'bvq_fakequant_bwd_shard')
+        if _timer is not None:
+            _timer.after('bvq_fakequant_bwd')
+    return dx, msg, pos
+
+
+def shard_unpack_deposit(x, dx, gathered, world, channels, rank, first_pos, inner, scale_dtype, int_threshold,
+                         quot_dtype, pre_op=PRE_NONE, want_dscale=False):
+    """after the all-gather: the shards' dscale sums added in double, the owner's deposit on dx in place (include/bvq.h);
+    -> float32 dscale_total [channels] if asked"""
+    dev = require_device(x, dx, gathered, first_pos)
+    assert gathered.dtype == torch.float64 and gathered.is_contiguous() and gathered.numel() == world * 2 * channels
+    ds = torch.empty(channels, dtype=torch.float32, device=dev) if want_dscale else None
+    with _DeviceGuard(dev):
+        check(lib.bvq_shard_unpack_deposit(dtype_code(x.dtype), ptr(x), ptr(dx), ptr(gathered), int(world), channels,
+                                           int(rank), ptr(first_pos), inner, dtype_code(scale_dtype),
+                                           float(int_threshold), dtype_code(quot_dtype), pre_op, ptr(ds),
+                                           stream_ptr(dev)), 'bvq_shard_unpack_deposit')
+    return ds
 
 
 def shard_pack(ds, tie_info, channels, rank, per_channel):
@@ -670,12 +779,21 @@ def fakequant_bwd_stats(desc, g, x, scale, zp, stat, scale_dtype, int_threshold,
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     stat = stat.to(x.dtype).contiguous()
     with _DeviceGuard(dev):
+        st = stream_ptr(dev)
+        arrive = None
+        if ONEPASS_BWD and lib.bvq_fakequant_bwd_stats_onepass_supported(ctypes.byref(desc)):
+            arrive = arrival_buffer(dev, st, int(desc.channels))
         if _timer is not None:
             _timer.before('bvq_fakequant_bwd')
-        check(lib.bvq_fakequant_bwd_stats(ctypes.byref(desc), ptr(g), ptr(x), ptr(scale), ptr(zp), ptr(stat), ptr(dx),
-                                          ptr(ds), dtype_code(scale_dtype), float(int_threshold),
-                                          dtype_code(quot_dtype), ptr(ws), wsb, stream_ptr(dev)),
-              'bvq_fakequant_bwd_stats')
+        if arrive is not None:  # one launch: the wave that completes a channel finishes it
+            check(lib.bvq_fakequant_bwd_stats_onepass(ctypes.byref(desc), ptr(g), ptr(x), ptr(scale), ptr(zp), ptr(stat),
+                                                      ptr(dx), ptr(ds), dtype_code(scale_dtype), float(int_threshold),
+                                                      dtype_code(quot_dtype), ptr(ws), wsb, ptr(arrive), arrive.numel(),
+                                                      st), 'bvq_fakequant_bwd_stats_onepass')
+        else:
+            check(lib.bvq_fakequant_bwd_stats(ctypes.byref(desc), ptr(g), ptr(x), ptr(scale), ptr(zp), ptr(stat), ptr(dx),
+                                              ptr(ds), dtype_code(scale_dtype), float(int_threshold),
+                                              dtype_code(quot_dtype), ptr(ws), wsb, st), 'bvq_fakequant_bwd_stats')
         if _timer is not None:
             _timer.after('bvq_fakequant_bwd')
     return (dx, ds) if want_dscale else dx

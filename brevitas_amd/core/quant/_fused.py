@@ -347,7 +347,7 @@ def stats_scale(flat: Tensor, int_threshold: Tensor, sp, group, pre_op, running=
     """AbsMax statistic of the [outer, channels, inner] tensor `flat` and the scale derived from it:
     -> (stat [channels] in x's dtype, scale shaped sp.scaling_shape).  group: the tensor is one batch shard.
     running: (buffer, momentum, first_batch) of a _RuntimeStats to fold the statistic into in the same launch
-    (unsharded route only; the caller checks `running_folded`)."""
+    (sharded: the statistic -> scale launch behind the all-reduce)."""
     if group is None:
         # statistic -> clamp_min -> / int_threshold in the reduction's own finishing launch.
         # torch's promotion: a dimensioned threshold keeps its dtype (the 0-dim float32
@@ -375,7 +375,11 @@ def stats_scale(flat: Tensor, int_threshold: Tensor, sp, group, pre_op, running=
     else:
         scale_dtype = torch.promote_types(flat.dtype, int_threshold.dtype)
         thr_div = sp.int_threshold
-    stat, scale = nat.scale_from_stat(stat32, flat.dtype, sp.min_val, thr_div, scale_dtype)
+    if running is not None:
+        buf, momentum, first = running
+        stat, scale = nat.scale_from_stat(stat32, flat.dtype, sp.min_val, thr_div, scale_dtype, buf, momentum, first)
+    else:
+        stat, scale = nat.scale_from_stat(stat32, flat.dtype, sp.min_val, thr_div, scale_dtype)
     return stat, scale.view(sp.scaling_shape)
 
 
@@ -418,7 +422,7 @@ class StatsFakeQuantFn(Function):
             # _RuntimeStats' running average rides on the statistic's finishing launch when its buffer is a plain
             # [channels] device tensor (the module is told through `bvq_running_folded`)
             running = None
-            if runtime is not None and group is None:
+            if runtime is not None:
                 buf = runtime.running_stats
                 if buf.is_cuda and buf.is_contiguous() and buf.numel() == sp.channels and buf.dtype in _FLOATS:
                     running = (buf, runtime.momentum, runtime.first_batch)
@@ -466,6 +470,24 @@ def stats_backward(xc, scale, zp, stat, int_threshold, desc, sp, group, pre_op, 
         dx = nat.fakequant_bwd_stats(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), stat,
                                      scale.dtype, thr_div, scale.dtype)
         if dx is not None:
+            return _restore(dx, back)
+    if group is not None and gscale is None and sp.channels > 1 and scale.numel() == sp.channels:
+        # batch shard, per-channel scale: the backward kernel (its last-arriving wave per channel writes the shard's
+        # all-gather message: double dscale sums + the claim on the deposit), ONE all-gather, one launch that adds the
+        # shards' sums in double and deposits the statistic's gradient on the owning shard
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        out = nat.fakequant_bwd_shard(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), stat, rank)
+        if out is not None:
+            dx, msg, pos = out
+            if world > 1:
+                gathered = torch.empty(world * msg.numel(), dtype=msg.dtype, device=msg.device)
+                dist.all_gather_into_tensor(gathered, msg, group=group)
+            else:
+                gathered = msg
+            thr_div = _as_dtype_value(sp.int_threshold, scale.dtype)
+            nat.shard_unpack_deposit(xc.reshape(-1), dx.reshape(-1), gathered, world, sp.channels, rank, pos, sp.inner,
+                                     scale.dtype, thr_div, scale.dtype, pre_op)
             return _restore(dx, back)
     # one pass: dx, the scale-gradient sums and the positions attaining the statistic
     dx, ds, _, ties = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), True,

@@ -176,11 +176,13 @@ __device__ __forceinline__ vec_t<T, N> buf_load(buf_t b, uint32_t byte_off) {
     return __builtin_bit_cast(vec_t<T, N>, __builtin_amdgcn_raw_buffer_load_b16(b, byte_off, 0, kAux));
   }
 }
-template <typename T, int N, bool NT = false>
+// SC1: agent-scope write-through (the `sc1` bit, aux bit 4 on gfx940+): the bytes are in the memory every XCD reads
+// once the wave's vmcnt has counted the store down, and the line does not stay in this XCD's L2
+template <typename T, int N, bool NT = false, bool SC1 = false>
 __device__ __forceinline__ void buf_store(buf_t b, uint32_t byte_off, const vec_t<T, N>& v) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  constexpr int kAux = NT ? 2 : 0;
+  constexpr int kAux = (NT ? 2 : 0) | (SC1 ? 16 : 0);
   if constexpr (sizeof(T) * N == 16) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b, byte_off, 0, kAux);
   } else if constexpr (sizeof(T) * N == 32) {
@@ -324,7 +326,7 @@ static inline unsigned grid_for_units(int64_t units) {
 }
 
 #ifdef __HIPCC__
-// One wave's unit, decoded from blockIdx / wave id (wave-uniform values: scalar registers).
+// One wave's unit (wave-uniform values: scalar registers).
 struct Unit {
   int64_t id;          // unit index (slot of its partial results)
   int64_t base;        // element offset of the unit's first element
@@ -337,10 +339,9 @@ struct Unit {
   bool valid;
 };
 
-__device__ __forceinline__ Unit locate_unit(const Tiling& t) {
+// the unit in dispatch slot `slot` (wave-uniform)
+__device__ __forceinline__ Unit locate_unit_slot(const Tiling& t, int64_t slot) {
   Unit u;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t slot = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   u.valid = slot < t.units;
   u.id = t.reverse ? t.units - 1 - slot : slot;  // the unit's id (slot of its partials) stays its position in memory
   if (!u.valid) {
@@ -383,6 +384,12 @@ __device__ __forceinline__ Unit locate_unit(const Tiling& t) {
   u.base = (o0 * t.channels + u.channel) * t.row_len + off;
   u.pos0 = o0 * t.row_len + off;
   return u;
+}
+
+// One wave's unit, decoded from blockIdx / wave id
+__device__ __forceinline__ Unit locate_unit(const Tiling& t) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  return locate_unit_slot(t, (int64_t)blockIdx.x * kWavesPerBlock + wave);
 }
 
 // Per-lane walk over the VEC-element chunks of a unit: chunk k of the unit (k = lane, lane+64, ...)

@@ -233,7 +233,11 @@ Tiling make_tiling(int64_t outer, int32_t channels, int64_t row_len, int vec, in
       const int64_t cap_chunks = 8 * (int64_t)default_piece_chunks() * kWave;
       int64_t best = 1;
       double best_eff = 0.0;
+      // (read-only kernels: never so many rows per unit that the launch has fewer than kMinUnits units -- a
+      //  [32,512,56,56] shard walked 8 rows at a time is 2048 waves on 1024 SIMDs and streamed at 2.2 TB/s)
+      constexpr int64_t kMinUnits = 16384;
       for (int64_t r = 1; r <= outer && r <= max_rows_per_unit() && r * cpr <= cap_chunks; ++r) {
+        if (!few_rows && r > 1 && ((outer + r - 1) / r) * channels < kMinUnits) break;
         const int64_t loads = (r * cpr + kWave - 1) / kWave;
         const double eff = (double)(r * cpr) / (double)(loads * kWave);
         if (eff > best_eff + 1e-9) {

@@ -36,6 +36,21 @@ struct QuantArgs {
   int32_t round_mode;
   int32_t pre_relu;  // x is passed through torch.relu first (FusedActivationQuantProxy)
   int32_t codes_dtype;
+  // bwd only, kBwdDsArrive (the stats-scaled backward in one launch): per-channel arrival counters, zero on entry
+  // and on exit; the wave that completes a channel sums its partials, turns dscale into the statistic's gradient and
+  // deposits it on the arg-max element of dx
+  uint32_t* arrive;
+  uint32_t arrive_per_channel;  // units of one channel
+  float* dscale_out;            // [channels]
+  int32_t gs_scale_dtype, gs_quot_dtype;  // GstatSrc of the deposit (bvq_ties.h)
+  float gs_int_threshold;
+  // batch-sharded tensors: instead of the deposit, the finishing wave writes this shard's message for the backward
+  // all-gather -- float64 [2][channels]: the channel's dscale sum (NOT rounded to float32: the sums of all shards are
+  // added in double and rounded once) and its claim on the deposit (shard_rank, or 2^30 with no arg-max here) -- and the
+  // first arg-max position (-1: none) for bvq_shard_unpack_deposit
+  double* shard_msg;
+  long long* shard_pos;
+  int32_t shard_rank;
 };
 
 #ifndef BVQ_FWD_UNROLL
@@ -724,7 +739,12 @@ __global__ __launch_bounds__(kFusedMaxWaves * kWave) void fused_absmax_fakequant
 // MODE: 0 = dx only, 1 = + dscale, 2 = + dscale and dzp, 3 = + dscale and abs-max tie search,
 // 4 = + dscale and the gradients of the clamp bounds (a learned bit width with a plain TensorClamp: the two
 //     torch.where of tensor_clamp send the gradient of a replaced value to the bound that replaced it).
-enum { kBwdDx = 0, kBwdDs = 1, kBwdDsDzp = 2, kBwdDsTies = 3, kBwdDsBounds = 4 };
+// 5 = mode 3 finished in the same launch (per-channel layouts): dx stores and the per-unit partials are written
+//     through (sc1), every wave counts itself in on its channel's arrival counter, and the wave that completes the
+//     channel does what bwd_stats_finish_kernel does in a second launch.  Nobody waits.
+enum { kBwdDx = 0, kBwdDs = 1, kBwdDsDzp = 2, kBwdDsTies = 3, kBwdDsBounds = 4, kBwdDsArrive = 5 };
+template <int MODE>
+constexpr bool kTieMode = MODE == kBwdDsTies || MODE == kBwdDsArrive;
 
 template <typename CT, int RM, int MODE, bool ZP0, typename Div>
 __device__ __forceinline__ float bwd_elem(float xf, float gf, const Div& div, float s, float z, float qmin,
@@ -757,19 +777,70 @@ __device__ __forceinline__ float bwd_elem(float xf, float gf, const Div& div, fl
 }
 
 // bwd_elem on a pair of elements; the sums are kept as pairs too (added up once per unit)
-template <typename CT, int RM, int MODE, bool ZP0, bool SAME16, typename Div, typename S>
+//
+// BVQ_BWD_LEAN (round 3; the kernel issued 23 VALU instructions per element, 88 % VALU-busy at the 2-read-1-write
+// ceiling -- profiles/r02/pmc_final_build.md): the same values with fewer instructions --
+//  * the clamp is v_med3_f32 and the pass mask ONE compare, "not (clamped <> rounded)" (true for equal and for NaN,
+//    as the reference's two `where` leave a NaN in place and pass its gradient): 2 instructions per element
+//    instead of 2 compares + 2 selects.  (A NaN element's clamped value differs -- med3 returns a bound -- but it
+//    only feeds term1 of a dscale sum that term2 = -dt * ((x / s) / s) has made NaN already.)
+//  * with a zero zero-point the backward needs no "+ 0.0": it only turns -0 into +0, which no comparison, no
+//    gradient value and no sum can see;
+//  * bf16: the two rounded terms of the scale gradient are ADDED by v_dot2c_f32_bf16 (acc += lo * 1 + hi * 1) straight
+//    from the packed conversion: no unpacking (two shifts / masks per pair) and no packed add.  Term 1 and term 2 go
+//    to the two halves of the pair accumulator: two independent chains.
+#ifndef BVQ_BWD_LEAN
+#define BVQ_BWD_LEAN 1
+#endif
+// acc + RN_bf16(v.x) + RN_bf16(v.y)
+__device__ __forceinline__ float add_rounded_pair_bf16(float acc, f2 v) {
+  typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 ones = {(bf16_t)1.0f, (bf16_t)1.0f};
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_convertvector(v, bf16x2), ones, acc, false);
+}
+// {acc.x + RN_bf16(v.x), acc.y + RN_bf16(v.y)}: the column-mapped kernels keep one sum per element of the pair.
+// The selectors {1, 0} and {0, 1} must live in registers the compiler cannot see through: as a constant, {1.0bf16, 0}
+// = 0x00003f80 is emitted as the inline constant "1.0", which the instruction reads as 0x3f800000 = {0, 1.0bf16}
+// (ROCm 7.2 / gfx950: both sums then received the pair's second element).  make_dot_sel() once per kernel.
+struct DotSel {
+  uint32_t lo, hi;
+};
+__device__ __forceinline__ DotSel make_dot_sel() {
+  DotSel d = {0x00003f80u, 0x3f800000u};
+  asm volatile("" : "+s"(d.lo), "+s"(d.hi));
+  return d;
+}
+__device__ __forceinline__ f2 add_rounded_lanes_bf16(f2 acc, f2 v, const DotSel& sel) {
+  typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 p = __builtin_convertvector(v, bf16x2);
+  return f2{__builtin_amdgcn_fdot2_f32_bf16(p, __builtin_bit_cast(bf16x2, sel.lo), acc.x, false),
+            __builtin_amdgcn_fdot2_f32_bf16(p, __builtin_bit_cast(bf16x2, sel.hi), acc.y, false)};
+}
+// MIX: the caller adds the two halves of ds_acc up in the end (row-mapped units: one channel per wave), so the sums
+// of the pair's elements may share an accumulator; otherwise ds_acc.x / .y stay the sums of element x / y.
+template <typename CT, int RM, int MODE, bool ZP0, bool SAME16, bool MIX = false, typename Div, typename S>
 __device__ __forceinline__ f2 bwd_elem2(f2 xf, f2 gf, const Div& div, S s, S z, float qmin, float qmax,
-                                        bool clamp_ste, int mode, f2& ds_acc, f2& dzp_acc, f2& dq_acc) {
+                                        bool clamp_ste, int mode, f2& ds_acc, f2& dzp_acc, f2& dq_acc,
+                                        const DotSel& sel = DotSel{}) {
   const f2 t1 = rnd2<CT>(div(xf));
-  const f2 t2 = ZP0 ? t1 + 0.f : rnd2<CT>(t1 + z);
+  constexpr bool kLean = BVQ_BWD_LEAN && MODE != kBwdDsBounds;
+  const f2 t2 = ZP0 ? (kLean ? t1 : t1 + 0.f) : rnd2<CT>(t1 + z);
   const f2 t3 = do_round2<CT, RM>(t2, mode);
   const f2 qhi = splat2(qmax), qlo = splat2(qmin);
-  const b2 hi = t3 > qhi;
-  f2 t4 = hi ? qhi : t3;
-  const b2 lo = t4 < qlo;
-  t4 = lo ? qlo : t4;
+  f2 t4;
+  b2 hi, lo, pass;
   const b2 all = {-1, -1};
-  const b2 pass = clamp_ste ? all : ~(hi | lo);
+  if constexpr (kLean) {
+    t4 = f2{__builtin_amdgcn_fmed3f(t3.x, qmin, qmax), __builtin_amdgcn_fmed3f(t3.y, qmin, qmax)};
+    const b2 same = {__builtin_islessgreater(t4.x, t3.x) ? 0 : -1, __builtin_islessgreater(t4.y, t3.y) ? 0 : -1};
+    pass = clamp_ste ? all : same;
+  } else {
+    hi = t3 > qhi;
+    t4 = hi ? qhi : t3;
+    lo = t4 < qlo;
+    t4 = lo ? qlo : t4;
+    pass = clamp_ste ? all : ~(hi | lo);
+  }
   const f2 gs = rnd2<CT>(gf * s);
   const f2 dt = pass ? gs : splat2(0.f);
   // rounded to CT, then stored as XT by the caller's pack2: when both are the same 16-bit type that second
@@ -780,10 +851,19 @@ __device__ __forceinline__ f2 bwd_elem2(f2 xf, f2 gf, const Div& div, S s, S z, 
     // (every product rounded to CT like the reference's ops.  Keeping the two terms in float32 would save three
     //  roundings per element, but the compiler then holds 25 more registers live -- 117 instead of 92 at depth 4,
     //  one wave per SIMD less -- and the kernel is no faster: profiles/r02_backward_variants.txt)
-    const f2 term1 = rnd2<CT>(gf * t5);
-    const f2 term2 = rnd2<CT>(-dt * rnd2<CT>(div(t1)));
-    ds_acc += term1;
-    ds_acc += term2;
+    if constexpr (kLean && elem<CT>::id == BVQ_BF16 && MIX) {
+      const float a1 = add_rounded_pair_bf16(ds_acc.x, gf * t5);
+      const float a2 = add_rounded_pair_bf16(ds_acc.y, -dt * rnd2<CT>(div(t1)));
+      ds_acc = f2{a1, a2};
+    } else if constexpr (kLean && elem<CT>::id == BVQ_BF16) {
+      ds_acc = add_rounded_lanes_bf16(ds_acc, gf * t5, sel);
+      ds_acc = add_rounded_lanes_bf16(ds_acc, -dt * rnd2<CT>(div(t1)), sel);
+    } else {
+      const f2 term1 = rnd2<CT>(gf * t5);
+      const f2 term2 = rnd2<CT>(-dt * rnd2<CT>(div(t1)));
+      ds_acc += term1;
+      ds_acc += term2;
+    }
   }
   if constexpr (MODE == kBwdDsDzp) dzp_acc += dt - gs;
   if constexpr (MODE == kBwdDsBounds) {
@@ -791,6 +871,119 @@ __device__ __forceinline__ f2 bwd_elem2(f2 xf, f2 gf, const Div& div, S s, S z, 
     dq_acc += hi ? gs : splat2(0.f);   // d(qmax)
   }
   return dxv;
+}
+
+// ---- the stats-scaled backward finished in the same launch (kBwdDsArrive) ------------------------------------------
+// a store / load that is performed at agent scope (global_store / global_load ... sc1): written through to, read from
+// the memory every XCD sees (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores and sc1 loads on both sides
+// of a hand-off, the storing wave's vmcnt(0) wait before its arrival add)
+template <typename T>
+__device__ __forceinline__ void store_through(T* p, T v) {
+  if constexpr (sizeof(T) == 2) {
+    __hip_atomic_store(reinterpret_cast<uint16_t*>(p), __builtin_bit_cast(uint16_t, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <typename T>
+__device__ __forceinline__ T load_through(const T* p) {
+  if constexpr (sizeof(T) == 2) {
+    return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const uint16_t*>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT));
+  } else {
+    return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT));
+  }
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)b, off, kWave);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(b >> 32), off, kWave);
+    v += __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);  // a butterfly: every lane ends with the same bits
+  }
+  return v;
+}
+
+// One wave finishes channel c of the stats-scaled backward from the units' partials (written through by their waves,
+// read through here): sum of the dscale partials (double, fixed order: lane l takes partials l, l + 64, ... in order,
+// then a butterfly), first position attaining the statistic; then either dscale -> statistic's gradient (the backward
+// of scale = clamp_min_ste(stat) / int_threshold with torch's rounding points) and its deposit on that element of dx,
+// or (batch-sharded tensors) this shard's message for the all-gather.
+template <typename XT, bool PRE>
+__device__ __forceinline__ void channel_finish(const QuantArgs& a, int32_t c, int lane) {
+  const uint32_t* pos32 = reinterpret_cast<const uint32_t*>(a.pos_part);
+  const int64_t n = (int64_t)a.arrive_per_channel;
+  const int64_t ppr = a.t.ppr;
+  double acc = 0.0;
+  unsigned long long pmin = ~0ull;
+  for (int64_t k = lane; k < n; k += kWave) {
+    int64_t unit;
+    if (a.t.nob == 1) {
+      unit = (int64_t)c * ppr + k;
+    } else {
+      const int64_t o = k / ppr, p = k - o * ppr;
+      unit = (o * a.t.channels + c) * ppr + p;
+    }
+    acc += (double)load_through<float>(a.ds_part + unit);
+    const unsigned long long q = (unsigned long long)load_through<uint32_t>(pos32 + 2 * unit) |
+                                 ((unsigned long long)load_through<uint32_t>(pos32 + 2 * unit + 1) << 32);
+    pmin = q < pmin ? q : pmin;
+  }
+  acc = wave_sum_f64(acc);
+  pmin = wave_min_u64(pmin);
+  if (lane != 0) return;
+  if (a.shard_msg) {
+    a.shard_msg[c] = acc;
+    a.shard_msg[a.t.channels + c] = pmin != ~0ull ? (double)a.shard_rank : kShardNoOwner;
+    a.shard_pos[c] = pmin != ~0ull ? (long long)pmin : -1ll;
+    return;
+  }
+  const float dsum = (float)acc;
+  a.dscale_out[c] = dsum;
+  if (pmin != ~0ull) {  // ~0: no element equals the statistic (e.g. NaN)
+    float v = round_rt(dsum, a.gs_scale_dtype);
+    v = round_rt(v / a.gs_int_threshold, a.gs_quot_dtype);
+    const float g = rnd<XT>(v);
+    const unsigned long long inner = (unsigned long long)a.t.row_len;
+    const int64_t o = (int64_t)(pmin / inner);
+    const int64_t i = (int64_t)(pmin - (unsigned long long)o * inner);
+    const int64_t flat = (o * a.t.channels + c) * (int64_t)inner + i;
+    const XT* xp = reinterpret_cast<const XT*>(a.x);
+    XT* dp = reinterpret_cast<XT*>(a.y);
+    const float term = deposit<XT, BVQ_MATCH_ABS>(g, xp[flat], PRE);
+    store_through<XT>(dp + flat, from_f<XT>(to_f<XT>(load_through<XT>(dp + flat)) + term));
+  }
+}
+
+// One wave has finished its unit: publish the unit's partials, count the unit in, and -- if that completes the
+// channel -- finish the channel: sum of the dscale partials (double, fixed order: lane l takes partials l, l + 64, ...
+// in order, then a butterfly), first position attaining the statistic, dscale -> statistic's gradient (the backward of
+// scale = clamp_min_ste(stat) / int_threshold with torch's rounding points) and its deposit on that element of dx.
+// ds / first: the unit's wave-reduced dscale sum and first arg-max position (~0: none).
+template <typename XT, bool PRE>
+__device__ __forceinline__ void bwd_arrive(const QuantArgs& a, const Unit& u, float ds, unsigned long long first,
+                                           int lane) {
+  uint32_t* pos32 = reinterpret_cast<uint32_t*>(a.pos_part);
+  uint32_t last = 0;
+  if (lane == 0) {
+    store_through<float>(a.ds_part + u.id, ds);
+    store_through<uint32_t>(pos32 + 2 * u.id, (uint32_t)first);
+    store_through<uint32_t>(pos32 + 2 * u.id + 1, (uint32_t)(first >> 32));
+  }
+  // every store of this wave (dx chunks of all lanes, the partials) has been performed before the unit is counted in
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) {
+    const uint32_t before = __hip_atomic_fetch_add(a.arrive + u.channel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = before + 1u == a.arrive_per_channel ? 1u : 0u;
+  }
+  if (!__builtin_amdgcn_readfirstlane(last)) return;
+  // ---- last arriver of this channel (rare: once per channel) ----
+  if (lane == 0) __hip_atomic_store(a.arrive + u.channel, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // handed back as zero
+  channel_finish<XT, PRE>(a, u.channel, lane);
 }
 
 // NT: cache policy of the loads of g and the stores of dx; NTX: of the loads of x (the same unless stated)
@@ -807,7 +1000,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
   // abs-max tie search: |x| == statistic of this unit's channel
   uint32_t stat_bits = 0;
   const bool per_channel = a.t.channels > 1;
-  if constexpr (MODE == kBwdDsTies)
+  if constexpr (kTieMode<MODE>)
     stat_bits = abs_bits<XT>(reinterpret_cast<const XT*>(a.tie_stat)[u.channel]);
 
   float ds_acc = 0.f, dzp_acc = 0.f, dq_acc = 0.f;
@@ -830,7 +1023,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
       for (int k = 0; k < VEC; k += 2) {
         const f2 xraw = widen2<XT>(xv.v[k], xv.v[k + 1]);
         constexpr bool kSame16 = sizeof(CT) == 2 && sizeof(XT) == 2;  // then XT is CT (dispatch pairs)
-        f2 d = bwd_elem2<CT, RM, MODE, ZP0, kSame16>(PRE ? relu2(xraw) : xraw, widen2<CT>(gv.v[k], gv.v[k + 1]),
+        f2 d = bwd_elem2<CT, RM, MODE, ZP0, kSame16, true>(PRE ? relu2(xraw) : xraw, widen2<CT>(gv.v[k], gv.v[k + 1]),
                                             div, s, z, qmin, qmax, clamp_ste, mode, ds_acc2, dzp_acc2, dq_acc2);
         if constexpr (PRE) d = xraw > splat2(0.f) ? d : splat2(0.f);  // torch.relu backward: grad * (x > 0)
         pack2<XT>(d, dv.v[k], dv.v[k + 1]);
@@ -845,7 +1038,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
         dv.v[k] = from_f<XT>(d);
       }
     }
-    if constexpr (MODE == kBwdDsTies) {
+    if constexpr (kTieMode<MODE>) {
       // cheap chunk-level filter: a tie in this chunk needs the chunk's max |x| to reach the statistic
       if constexpr (sizeof(XT) == 2 && VEC % 2 == 0 && !PRE) {
         // two 16-bit keys per word: clear both sign bits, packed unsigned max (2 ops per pair)
@@ -866,7 +1059,9 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
         }
       }
     }
-    buf_store<XT, VEC, NT>(bd, off * (uint32_t)sizeof(XT), dv);  // dropped where off is kSkip
+    // (kBwdDsArrive: written through, so that the finishing wave -- maybe on another XCD -- finds every dx element in
+    //  memory: MI355X_MICROARCH.md, inter-workgroup visibility)
+    buf_store<XT, VEC, NT, MODE == kBwdDsArrive>(bd, off * (uint32_t)sizeof(XT), dv);  // dropped where off is kSkip
   };
   ChunkCursor cur;
   cur.init(u, VEC, lane);
@@ -934,7 +1129,7 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
       }
     }
   }
-  if constexpr (MODE == kBwdDsTies) {
+  if constexpr (kTieMode<MODE>) {
     // Rare: a handful of elements per channel attain the maximum.  The hot loop only tracked this lane's
     // largest key; a lane that saw the statistic walks its chunks once more (cold code, out of the hot
     // loop's register budget) and records the positions.
@@ -969,8 +1164,11 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
     float d = bwd_elem<CT, RM, MODE, ZP0>(PRE ? relu_f(xraw) : xraw, to_f<CT>(gp[i]), div, s, z, qmin, qmax,
                                           clamp_ste, mode, ds_acc, dzp_acc, dq_acc);
     if constexpr (PRE) d = xraw > 0.f ? d : 0.f;
-    dxp[i] = from_f<XT>(d);
-    if constexpr (MODE == kBwdDsTies) {
+    if constexpr (MODE == kBwdDsArrive)
+      store_through<XT>(dxp + i, from_f<XT>(d));
+    else
+      dxp[i] = from_f<XT>(d);
+    if constexpr (kTieMode<MODE>) {
       if (pre_abs_bits<XT, PRE>(xp[i]) == stat_bits) {
         const unsigned long long p = (unsigned long long)(u.pos0 + (int64_t)tr * a.t.row_len + in_row);
         if (a.pos_part) {
@@ -981,7 +1179,14 @@ __device__ __forceinline__ void bwd_unit(const QuantArgs& a, const Unit& u, cons
       }
     }
   }
-  if constexpr (MODE == kBwdDsTies) {
+  if constexpr (MODE == kBwdDsArrive) {
+    ds_acc += ds_acc2.x + ds_acc2.y;
+    ds_acc = wave_sum(ds_acc);
+    tie_first = wave_min_u64(tie_first);
+    bwd_arrive<XT, PRE>(a, u, ds_acc, tie_first, lane);
+    return;
+  }
+  if constexpr (kTieMode<MODE>) {
     if (a.pos_part) {  // no atomics, nothing to initialise: the finishing kernel takes the minimum over units
       tie_first = wave_min_u64(tie_first);
       if (lane == 0) a.pos_part[u.id] = tie_first;
@@ -1094,6 +1299,7 @@ __device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const Cols
   const bool clamp_ste = a.clamp_ste != 0;
   const int mode = a.round_mode;
   // the work on one row of this lane's columns: rr = the row, cnt = how many rows this lane has seen before it
+  const DotSel dsel = make_dot_sel();
   auto row_work = [&](const vec_t<T, VEC>& xr, const vec_t<T, VEC>& gr, int64_t rr, uint32_t cnt) {
     vec_t<T, VEC> dv;
 #pragma unroll
@@ -1104,13 +1310,13 @@ __device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const Cols
       f2 d;
       if constexpr (FAST && elem<T>::id == BVQ_F16)
         d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, BVQ_DIVF16V{ln.s2[k / 2], r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2],
-                                                   qmin, qmax, clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
+                                                   qmin, qmax, clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused, dsel);
       else if constexpr (FAST)
         d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivBf16V{r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax,
-                                                   clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
+                                                   clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused, dsel);
       else
         d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivExactV{ln.s2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin,
-                                                   qmax, clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused);
+                                                   qmax, clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused, dsel);
       if (a.pre_relu) d = xraw > splat2(0.f) ? d : splat2(0.f);
       pack2<T>(d, dv.v[k], dv.v[k + 1]);
     }
@@ -1270,6 +1476,51 @@ __global__ __launch_bounds__(kBlock) void bwd_stats_finish_kernel(const float* _
       dp[flat] = from_f<T>(to_f<T>(dp[flat]) + term);
     }
   }
+}
+
+// channel_finish as its own launch: one wave per channel (the routes whose streaming kernel does not finish its
+// channels itself: column-mapped layouts, callers without an arrival buffer)
+template <typename XT>
+__global__ __launch_bounds__(kBlock) void channel_finish_kernel(QuantArgs a) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int32_t c = (int32_t)blockIdx.x * kWavesPerBlock + wave;
+  if (c >= a.t.channels) return;
+  if (a.pre_relu)
+    channel_finish<XT, true>(a, c, threadIdx.x & 63);
+  else
+    channel_finish<XT, false>(a, c, threadIdx.x & 63);
+}
+
+// Batch-sharded tensors, after the all-gather of the shards' messages (float64 [world][2][channels]): per channel the
+// dscale sums of all shards added in rank order (double, rounded to float32 ONCE: the same bits on every rank), the
+// deposit's owner = the lowest rank that holds an arg-max, and -- on the owner -- dscale -> statistic's gradient and
+// its deposit at this shard's first arg-max position.  Replaces unpack + cast + divide + cast + deposit launches.
+template <typename T>
+__global__ void shard_unpack_deposit_kernel(const double* __restrict__ all, int32_t world, int32_t channels, int32_t rank,
+                                            const long long* __restrict__ first_pos, const void* x, void* dx,
+                                            int64_t inner, GstatSrc gs, float* __restrict__ dscale_total) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= channels) return;
+  double sum = 0.0, owner = kShardNoOwner;
+  for (int r = 0; r < world; ++r) {
+    sum += all[((int64_t)r * 2) * channels + c];
+    const double o = all[((int64_t)r * 2 + 1) * channels + c];
+    owner = o < owner ? o : owner;
+  }
+  const float ds = (float)sum;
+  if (dscale_total) dscale_total[c] = ds;
+  const long long pos = first_pos[c];
+  if (owner != (double)rank || pos < 0) return;
+  float v = round_rt(ds, gs.scale_dtype);
+  v = round_rt(v / gs.int_threshold, gs.quot_dtype);
+  const float g = rnd<T>(v);
+  const int64_t o = (int64_t)(pos / inner);
+  const int64_t i = (int64_t)(pos - o * inner);
+  const int64_t flat = (o * channels + c) * inner + i;
+  const T* xp = reinterpret_cast<const T*>(x);
+  T* dp = reinterpret_cast<T*>(dx);
+  const float term = deposit<T, BVQ_MATCH_ABS>(g, xp[flat], gs.pre_relu != 0);
+  dp[flat] = from_f<T>(to_f<T>(dp[flat]) + term);
 }
 
 #endif  // backward part
@@ -1474,6 +1725,9 @@ void launch_bwd(const QuantArgs& a, int vec, int mode, bool nt, hipStream_t st) 
       break;
     case kBwdDsBounds:
       launch_bwd_mode<XT, CT, kBwdDsBounds>(a, vec, nt, st);
+      break;
+    case kBwdDsArrive:
+      launch_bwd_mode<XT, CT, kBwdDsArrive>(a, vec, nt, st);
       break;
     default:
       launch_bwd_mode<XT, CT, kBwdDsTies>(a, vec, nt, st);
@@ -1961,10 +2215,103 @@ extern "C" int64_t bvq_fakequant_bwd_stats_workspace_bytes(const bvq_quant_desc*
   return units * (int64_t)(sizeof(float) + sizeof(unsigned long long)) + 256;
 }
 
+struct ShardOut {  // batch-sharded tensors: the all-gather message instead of the deposit (null: unsharded)
+  double* msg;
+  long long* pos;
+  int32_t rank;
+};
+static int bwd_stats_impl(const bvq_quant_desc* d, const void* g, const void* x, const void* scale, const void* zp,
+                          const void* stat, void* dx, float* dscale, int scale_dtype, double int_threshold,
+                          int quot_dtype, void* workspace, int64_t workspace_bytes, uint32_t* arrive,
+                          int64_t arrive_words, bvq_stream_t stream, const ShardOut* shard = nullptr);
+
 extern "C" int bvq_fakequant_bwd_stats(const bvq_quant_desc* d, const void* g, const void* x, const void* scale,
                                        const void* zp, const void* stat, void* dx, float* dscale,
                                        int scale_dtype, double int_threshold, int quot_dtype, void* workspace,
                                        int64_t workspace_bytes, bvq_stream_t stream) {
+  return bwd_stats_impl(d, g, x, scale, zp, stat, dx, dscale, scale_dtype, int_threshold, quot_dtype, workspace,
+                        workspace_bytes, nullptr, 0, stream);
+}
+
+extern "C" int bvq_fakequant_bwd_stats_onepass_supported(const bvq_quant_desc* d) {
+  int64_t units, per_channel;
+  if (validate(d) || !bwd_stats_supported(d, units, per_channel)) return 0;
+  if (cols_quant_plan(d, nullptr, nullptr, nullptr).ok) return 0;  // column-mapped layouts: two launches
+  return 1;
+}
+
+extern "C" int bvq_fakequant_bwd_stats_onepass(const bvq_quant_desc* d, const void* g, const void* x,
+                                               const void* scale, const void* zp, const void* stat, void* dx,
+                                               float* dscale, int scale_dtype, double int_threshold, int quot_dtype,
+                                               void* workspace, int64_t workspace_bytes, uint32_t* arrive,
+                                               int64_t arrive_words, bvq_stream_t stream) {
+  if (!arrive) {
+    set_error("bvq_fakequant_bwd_stats_onepass: null arrival buffer");
+    return BVQ_ERR_INVALID;
+  }
+  if (!bvq_fakequant_bwd_stats_onepass_supported(d)) {
+    set_error("bvq_fakequant_bwd_stats_onepass: layout not covered: use bvq_fakequant_bwd_stats");
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  if (arrive_words < d->channels) {
+    set_error("bvq_fakequant_bwd_stats_onepass: arrival buffer of %lld words, %lld needed", (long long)arrive_words,
+              (long long)d->channels);
+    return BVQ_ERR_WORKSPACE;
+  }
+  return bwd_stats_impl(d, g, x, scale, zp, stat, dx, dscale, scale_dtype, int_threshold, quot_dtype, workspace,
+                        workspace_bytes, arrive, arrive_words, stream);
+}
+
+extern "C" int bvq_fakequant_bwd_shard(const bvq_quant_desc* d, const void* g, const void* x, const void* scale,
+                                       const void* zp, const void* stat, void* dx, double* message, int64_t* first_pos,
+                                       int rank, void* workspace, int64_t workspace_bytes, uint32_t* arrive,
+                                       int64_t arrive_words, bvq_stream_t stream) {
+  if (!message || !first_pos || rank < 0) {
+    set_error("bvq_fakequant_bwd_shard: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  if (arrive && (!bvq_fakequant_bwd_stats_onepass_supported(d) || arrive_words < d->channels)) arrive = nullptr;
+  ShardOut so = {message, reinterpret_cast<long long*>(first_pos), rank};
+  float unused = 0.f;
+  return bwd_stats_impl(d, g, x, scale, zp, stat, dx, &unused, BVQ_F32, 1.0, BVQ_F32, workspace, workspace_bytes, arrive,
+                        arrive_words, stream, &so);
+}
+
+extern "C" int bvq_shard_unpack_deposit(int dtype, const void* x, void* dx, const double* gathered, int world,
+                                        int64_t channels, int rank, const int64_t* first_pos, int64_t inner,
+                                        int scale_dtype, double int_threshold, int quot_dtype, int pre_op,
+                                        float* dscale_total, bvq_stream_t stream) {
+  if (dtype < BVQ_F32 || dtype > BVQ_F16 || scale_dtype < BVQ_F32 || scale_dtype > BVQ_F16 || quot_dtype < BVQ_F32 ||
+      quot_dtype > BVQ_F16 || channels < 1 || world < 1 || rank < 0 || rank >= world || inner < 1 || !x || !dx ||
+      !gathered || !first_pos || !(int_threshold == int_threshold)) {
+    set_error("bvq_shard_unpack_deposit: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  GstatSrc gs = {};
+  gs.from_dscale = 1;
+  gs.scale_dtype = scale_dtype;
+  gs.quot_dtype = quot_dtype;
+  gs.int_threshold = (float)int_threshold;
+  gs.pre_relu = pre_op == BVQ_PRE_RELU;
+  const dim3 grid((unsigned)((channels + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const long long* fp = reinterpret_cast<const long long*>(first_pos);
+  if (dtype == BVQ_F32)
+    shard_unpack_deposit_kernel<float><<<grid, block, 0, st>>>(gathered, world, (int32_t)channels, rank, fp, x, dx, inner,
+                                                              gs, dscale_total);
+  else if (dtype == BVQ_BF16)
+    shard_unpack_deposit_kernel<bf16_t><<<grid, block, 0, st>>>(gathered, world, (int32_t)channels, rank, fp, x, dx, inner,
+                                                               gs, dscale_total);
+  else
+    shard_unpack_deposit_kernel<f16_t><<<grid, block, 0, st>>>(gathered, world, (int32_t)channels, rank, fp, x, dx, inner,
+                                                              gs, dscale_total);
+  return check_launch("bvq_shard_unpack_deposit");
+}
+
+static int bwd_stats_impl(const bvq_quant_desc* d, const void* g, const void* x, const void* scale, const void* zp,
+                          const void* stat, void* dx, float* dscale, int scale_dtype, double int_threshold,
+                          int quot_dtype, void* workspace, int64_t workspace_bytes, uint32_t* arrive,
+                          int64_t arrive_words, bvq_stream_t stream, const ShardOut* shard) {
   int rc = validate(d);
   if (rc) return rc;
   int64_t units, per_channel;
@@ -2026,6 +2373,21 @@ extern "C" int bvq_fakequant_bwd_stats(const bvq_quant_desc* d, const void* g, c
       unsigned long long* pos_fold = nullptr;
       launch_cols_fold_sum_min(ca.ds_part, ca.pos_part, cp.prows, cp.L, ca.ds_part + cp.prows * cp.L,
                                ca.pos_part + cp.prows * cp.L, &ds_fold, &pos_fold, st);
+      if (shard) {  // this shard's all-gather message from the folded partials: one wave per channel
+        QuantArgs fa = {};
+        fa.t.nob = 1;
+        fa.t.channels = channels;
+        fa.t.ppr = d->inner;
+        fa.arrive_per_channel = (uint32_t)d->inner;
+        fa.ds_part = ds_fold;
+        fa.pos_part = pos_fold;
+        fa.shard_msg = shard->msg;
+        fa.shard_pos = shard->pos;
+        fa.shard_rank = shard->rank;
+        const dim3 cgrid((unsigned)((channels + kWavesPerBlock - 1) / kWavesPerBlock));
+        channel_finish_kernel<float><<<cgrid, dim3(kBlock), 0, st>>>(fa);  // (the message path touches no tensor element)
+        return check_launch("bvq_fakequant_bwd_shard/cols_finish");
+      }
       const dim3 fgrid((unsigned)channels), fblock(kBlock);
       if (d->x_dtype == BVQ_F32)
         bwd_stats_finish_kernel<float><<<fgrid, fblock, 0, st>>>(ds_fold, pos_fold, dscale, gs, x, dx, 1, channels,
@@ -2062,11 +2424,33 @@ extern "C" int bvq_fakequant_bwd_stats(const bvq_quant_desc* d, const void* g, c
   a.y = dx;
   a.tie_stat = stat;
   fill_args(a, d);
+  a.arrive_per_channel = (uint32_t)(a.t.nob * a.t.ppr);
+  if (shard) {
+    a.shard_msg = shard->msg;
+    a.shard_pos = shard->pos;
+    a.shard_rank = shard->rank;
+  }
+  if (arrive) {  // one launch: the wave that completes a channel finishes it
+    a.arrive = arrive;
+    a.dscale_out = dscale;
+    a.gs_scale_dtype = scale_dtype;
+    a.gs_quot_dtype = quot_dtype;
+    a.gs_int_threshold = (float)int_threshold;
+#define BVQ_CALL(XT, CT) launch_bwd<XT, CT>(a, vec, kBwdDsArrive, nt, st)
+    BVQ_DISPATCH_PAIR(d, BVQ_CALL);
+#undef BVQ_CALL
+    return check_launch("bvq_fakequant_bwd_stats_onepass");
+  }
 #define BVQ_CALL(XT, CT) launch_bwd<XT, CT>(a, vec, kBwdDsTies, nt, st)
   BVQ_DISPATCH_PAIR(d, BVQ_CALL);
 #undef BVQ_CALL
   rc = check_launch("bvq_fakequant_bwd_stats");
   if (rc) return rc;
+  if (shard) {
+    const dim3 cgrid((unsigned)((channels + kWavesPerBlock - 1) / kWavesPerBlock));
+    channel_finish_kernel<float><<<cgrid, dim3(kBlock), 0, st>>>(a);  // (the message path touches no tensor element)
+    return check_launch("bvq_fakequant_bwd_shard/finish");
+  }
   const dim3 grid((unsigned)channels), block(kBlock);
   if (d->x_dtype == BVQ_F32)
     bwd_stats_finish_kernel<float><<<grid, block, 0, st>>>(a.ds_part, a.pos_part, dscale, gs, x, dx, a.t.nob, channels,

@@ -497,6 +497,126 @@ __global__ __launch_bounds__(kBlock) void stat_finish_kernel(const uint32_t* __r
   }
 }
 
+// ---- abs-max in ONE launch (per-channel layouts) ----------------------------------------------------------------
+// Persistent waves walk the units with a grid stride; a wave keeps one running maximum for as long as its units
+// belong to one channel (the grid is sized so that they always do when the layout allows), then ARRIVES: an atomic
+// max into the channel's key word, and -- once that has returned -- an atomic add of the units it covered into the
+// channel's counter.  The wave whose add completes the channel reads the key back and finishes the channel
+// (statistic, scale epilogue, running statistic: what stat_finish_kernel does in a second launch).  Nobody waits:
+// only the last arriver does the extra work.  A max is exact and order-independent, so the result is the same bits
+// whoever arrives last.  Both words are handed back as zeros (exchange / store by the finishing lane), so the
+// caller's arrival buffer needs no clearing between launches on one stream.
+// (MI355X_MICROARCH.md, inter-workgroup visibility: agent-scope atomics both sides; no plain load of another
+//  workgroup's stores anywhere.)
+struct ArriveArgs {
+  uint32_t* key;         // [channels] zero on entry and on exit
+  uint32_t* cnt;         // [channels] zero on entry and on exit
+  uint32_t per_channel;  // units of one channel
+  void* stat_out;
+  int32_t stat_dtype, in_dtype;
+};
+
+__device__ __forceinline__ void absmax_arrive(const ArriveArgs& r, const ScaleEpilogue& ep, int32_t c, uint32_t m,
+                                              uint32_t n, int lane) {
+  m = wave_max_u32(m);
+  if (lane != 0) return;
+  const uint32_t seen = __hip_atomic_fetch_max(r.key + c, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t add = n;
+  asm volatile("" : "+v"(add) : "v"(seen));  // the count is added only after the max has been performed (returned)
+  const uint32_t before = __hip_atomic_fetch_add(r.cnt + c, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (before + add != r.per_channel) return;
+  // last arriver of channel c: every other wave's max was performed before its add, and all adds before this one
+  const uint32_t bits = __hip_atomic_exchange(r.key + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(r.cnt + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float v = r.in_dtype == BVQ_F16 ? (float)__builtin_bit_cast(f16_t, (uint16_t)bits)
+                                         : __builtin_bit_cast(float, bits);
+  store_stat(r.stat_out, r.stat_dtype, c, v);
+  if (ep.scale_out) {
+    const float thr = (ep.use_min && v < ep.min_val) ? ep.min_val : v;  // NaN passes, like torch.clamp_min
+    store_stat(ep.scale_out, ep.scale_dtype, c, thr / ep.int_threshold);
+  }
+  if (ep.running) {
+    const float run = load_scalar_as_f(ep.running, ep.run_dtype, c);
+    store_stat(ep.running, ep.run_dtype, c,
+               running_update(run, v, ep.run_dtype, r.stat_dtype, ep.one_minus_m, ep.momentum, ep.first_batch));
+  }
+}
+
+// One LONG unit per wave (onepass_tiling: ~8192 waves per launch, each walking tens of rows of its channel), walked as a
+// software pipeline: kOnepassDepth 16-byte chunks per lane are always in flight, the load of chunk i + depth is issued
+// as chunk i is folded into the running maximum.  Buffer loads with an out-of-range offset for the lanes past the
+// unit's end return zeros without touching memory (|0| never raises a maximum), so the loop has no branch and no
+// predicated load.  (The first form of this kernel -- persistent waves over the two-launch kernel's short units, each
+// a load-all / wait / fold batch behind a predicate -- streamed at 5.2 TB/s where the two-launch kernel reaches 6.6:
+// profiles/r03_onepass.txt.)
+// (depth 4 / 8 and 6144 / 8192 / 12288 units all stream within 1.5 us of each other on [256,512,56,56] bf16, depth 16
+//  spills and crawls: profiles/r03_onepass.txt)
+constexpr int kOnepassDepth = 4;
+
+template <typename T, int VEC, bool NT, bool RELU>
+__global__ __launch_bounds__(kBlock) void absmax_onepass_kernel(StatArgs a, ArriveArgs r, ScaleEpilogue ep) {
+  const Unit u = locate_unit(a.t);
+  if (!u.valid) return;
+  const int lane = threadIdx.x & 63;
+  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + u.base;
+  const int64_t extent = (int64_t)(u.nrows - 1) * u.row_stride + u.len;
+  const buf_t bx = make_buf(xp, (uint32_t)(extent * (int64_t)sizeof(T)));
+  constexpr uint32_t kSkip = 0x60000000u;  // element offset whose byte offset is >= 2^31 for 2- and 4-byte elements
+  constexpr int kD = kOnepassDepth;
+  ChunkCursor cur;
+  cur.init(u, VEC, lane);
+  const int64_t total = (int64_t)u.nrows * cur.cpr;
+  const int32_t steps = (int32_t)((total + kWave - 1) / kWave);
+  const uint32_t rs = (uint32_t)u.row_stride;
+  uint32_t m = 0;
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  u16x2 m2 = {0, 0};
+  auto fold = [&](const vec_t<T, VEC>& xv) {
+    if constexpr (sizeof(T) == 2 && VEC % 2 == 0 && !RELU) {
+      // two 16-bit keys per word: clear both sign bits, packed unsigned max
+      const vec_t<uint32_t, VEC / 2> w = __builtin_bit_cast(vec_t<uint32_t, VEC / 2>, xv);
+#pragma unroll
+      for (int k = 0; k < VEC / 2; ++k)
+        m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, w.v[k] & 0x7fff7fffu));
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const uint32_t b = pre_abs_bits<T, RELU>(xv.v[k]);
+        m = b > m ? b : m;
+      }
+    }
+  };
+  vec_t<T, VEC> xb[kD];
+#pragma unroll
+  for (int j = 0; j < kD; ++j) {
+    const uint32_t off = cur.valid() ? cur.offset32(rs, VEC) : kSkip;
+    xb[j] = buf_load<T, VEC, NT>(bx, off * (uint32_t)sizeof(T));
+    cur.next();
+  }
+  for (int32_t base = 0; base < steps; base += kD) {
+#pragma unroll
+    for (int j = 0; j < kD; ++j) {
+      if (base + j >= steps) break;  // wave-uniform
+      fold(xb[j]);
+      const uint32_t off = cur.valid() ? cur.offset32(rs, VEC) : kSkip;
+      xb[j] = buf_load<T, VEC, NT>(bx, off * (uint32_t)sizeof(T));
+      cur.next();
+    }
+  }
+  if constexpr (sizeof(T) == 2 && VEC % 2 == 0 && !RELU) {
+    const uint32_t m16 = m2.x > m2.y ? m2.x : m2.y;
+    m = elem<T>::id == BVQ_BF16 ? (m16 << 16) : m16;  // the abs_bits<> key space
+  }
+  // ragged ends: the (< VEC) elements after the last full chunk of every row of the unit
+  const int32_t tail = (int32_t)(u.len - (int64_t)cur.cpr * VEC);
+  for (int32_t e = lane; e < u.nrows * tail; e += kWave) {
+    const int32_t tr = e / tail, k = e - tr * tail;
+    const uint32_t b = pre_abs_bits<T, RELU>(xp[(int64_t)tr * u.row_stride + (int64_t)cur.cpr * VEC + k]);
+    m = b > m ? b : m;
+  }
+  absmax_arrive(r, ep, u.channel, m, 1u, lane);
+}
+
 // ---- batch-sharded tensors: the bookkeeping around the two collectives, one launch each ---------------
 // (brevitas_amd/distributed.py holds the same logic as torch ops for CPU tensors: the gloo protocol test)
 //
@@ -504,7 +624,6 @@ __global__ __launch_bounds__(kBlock) void stat_finish_kernel(const uint32_t* __r
 //   row 0 = the shard's dscale partial sums, row 1 = its claim on each channel's deposit:
 //   per-channel / first-only layouts: `rank` if the shard holds an element attaining the statistic, else
 //   NO_OWNER; whole-tensor layouts: its number of ties.
-constexpr double kShardNoOwner = 1073741824.0;  // 2^30, above any rank
 
 __global__ void shard_pack_kernel(const float* __restrict__ ds, const long long* __restrict__ tie_info,
                                   double* __restrict__ out, int32_t channels, int32_t rank, int per_channel) {
@@ -551,6 +670,11 @@ __global__ void scale_from_stat_kernel(const float* __restrict__ stat32, void* s
   store_stat(stat_out, stat_dtype, c, v);
   const float thr = (ep.use_min && v < ep.min_val) ? ep.min_val : v;
   store_stat(ep.scale_out, ep.scale_dtype, c, thr / ep.int_threshold);
+  if (ep.running) {
+    const float r = load_scalar_as_f(ep.running, ep.run_dtype, c);
+    store_stat(ep.running, ep.run_dtype, c,
+               running_update(r, v, ep.run_dtype, stat_dtype, ep.one_minus_m, ep.momentum, ep.first_batch));
+  }
 }
 
 // Running average of a statistic, as _RuntimeStats keeps it (B/core/stats/stats_wrapper.py:61-66):
@@ -989,6 +1113,140 @@ extern "C" int bvq_absmax_scale(int pre_op, int dtype, const void* x, int64_t ou
                     workspace_bytes, stream);
 }
 
+// Units of the one-launch abs-max: long ones.  Short rows (NCHW activations): as many rows of one channel per wave as
+// leave ~kOnepassUnits waves in the launch (a wave's arrival -- two atomic round trips -- then costs a percent of its
+// life, not 7 %), taking the row count near that which wastes the fewest lanes of the 64-wide loads.  Long rows keep
+// their pieces.  A unit's extent stays below 2^31 bytes (32-bit buffer offsets).
+constexpr int64_t kOnepassUnits = 8192;
+
+static bool onepass_tiling(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner, Tiling& t,
+                           int& vec) {
+  t = stat_tiling(dtype, x, nullptr, outer, channels, inner, vec, true);
+  if (t.ppr == 1 && t.outer > 1) {
+    const int64_t cpr = t.row_len / vec;
+    static const int64_t target = env_flag("BVQ_ONEPASS_UNITS", (int)kOnepassUnits);  // developer knob (tools/onepass_ab.py)
+    int64_t r0 = t.outer * channels / target;
+    r0 = r0 < 1 ? 1 : (r0 > t.outer ? t.outer : r0);
+    int64_t best = r0;
+    double best_eff = -1.0;
+    for (int64_t rr = r0; rr >= 1 && 2 * rr > r0; --rr) {
+      const int64_t loads = (rr * cpr + kWave - 1) / kWave;
+      const double eff = loads > 0 ? (double)(rr * cpr) / (double)(loads * kWave) : 1.0;
+      if (eff > best_eff + 1e-9) {
+        best_eff = eff;
+        best = rr;
+      }
+      if (eff >= 0.97) break;
+    }
+    t.rpu = (int32_t)best;
+    t.nob = (t.outer + t.rpu - 1) / t.rpu;
+    t.units = t.nob * channels * t.ppr;
+  }
+  return cap_unit_extent(t, dtype_size(dtype));
+}
+
+static bool onepass_layout(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner) {
+  if (channels < 2 || outer < 1 || inner < 1) return false;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && cols_plan(dtype, outer, channels, inner).ok) return false;
+  return true;
+}
+
+extern "C" int bvq_absmax_onepass_supported(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner) {
+  if (bad_dtype(dtype)) return 0;
+  if (!onepass_layout(dtype, x, outer, channels, inner)) return 0;
+  int vec;
+  Tiling t;
+  if (!onepass_tiling(dtype, x, outer, channels, inner, t, vec)) return 0;
+  return t.nob * t.ppr < ((int64_t)1 << 31) ? 1 : 0;
+}
+
+extern "C" int bvq_absmax_scale_onepass(int pre_op, int dtype, const void* x, int64_t outer, int64_t channels,
+                                        int64_t inner, int stat_dtype, void* stat_out, double min_val, int use_min,
+                                        double int_threshold, int scale_dtype, void* scale_out, int run_dtype,
+                                        void* running, double momentum, int first_batch, uint32_t* arrive,
+                                        int64_t arrive_words, bvq_stream_t stream) {
+  if (pre_op != BVQ_PRE_NONE && pre_op != BVQ_PRE_RELU) {
+    set_error("bvq_absmax_scale_onepass: bad pre_op %d", pre_op);
+    return BVQ_ERR_INVALID;
+  }
+  if (bad_dtype(dtype) || bad_dtype(stat_dtype) || (scale_out && bad_dtype(scale_dtype)) ||
+      (running && bad_dtype(run_dtype)) || (scale_out && !(int_threshold == int_threshold))) {
+    set_error("bvq_absmax_scale_onepass: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  if (stat_dtype != BVQ_F32 && stat_dtype != dtype) {
+    set_error("bvq_absmax_scale_onepass: stat_dtype must be f32 or the dtype of x");
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  if (!x || !stat_out || !arrive) {
+    set_error("bvq_absmax_scale_onepass: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  if (!bvq_absmax_onepass_supported(dtype, x, outer, channels, inner)) {
+    set_error("bvq_absmax_scale_onepass: layout not covered (per-tensor or column-mapped): use bvq_absmax_scale");
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  if (arrive_words < 2 * channels) {
+    set_error("bvq_absmax_scale_onepass: arrival buffer of %lld words, %lld needed", (long long)arrive_words,
+              (long long)(2 * channels));
+    return BVQ_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = outer * channels * inner;
+  const bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
+  int vec;
+  StatArgs a = {};
+  onepass_tiling(dtype, x, outer, channels, inner, a.t, vec);
+  a.x = x;
+  ArriveArgs r;
+  r.key = arrive;
+  r.cnt = arrive + channels;
+  r.per_channel = (uint32_t)(a.t.nob * a.t.ppr);
+  r.stat_out = stat_out;
+  r.stat_dtype = stat_dtype;
+  r.in_dtype = dtype;
+  ScaleEpilogue ep = {};
+  if (scale_out) {
+    ep.scale_out = scale_out;
+    ep.scale_dtype = scale_dtype;
+    ep.use_min = use_min;
+    ep.min_val = round_host((float)min_val, dtype);  // python scalar -> the statistic's dtype
+    ep.int_threshold = (float)int_threshold;
+  }
+  if (running) {
+    ep.running = running;
+    ep.run_dtype = run_dtype;
+    ep.first_batch = first_batch;
+    // torch turns the python scalars (1 - momentum) and momentum into float32 for these dtypes (bvq_running_stats_update)
+    ep.one_minus_m = (float)(1.0 - momentum);
+    ep.momentum = (float)momentum;
+  }
+  const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
+  const bool relu = pre_op == BVQ_PRE_RELU;
+#define BVQ_ONEPASS(T)                                                              \
+  do {                                                                              \
+    constexpr int V = elem<T>::vec;                                                 \
+    if (relu && vec == V)                                                           \
+      absmax_onepass_kernel<T, V, false, true><<<grid, block, 0, st>>>(a, r, ep);   \
+    else if (relu)                                                                  \
+      absmax_onepass_kernel<T, 1, false, true><<<grid, block, 0, st>>>(a, r, ep);   \
+    else if (vec == V && nt)                                                        \
+      absmax_onepass_kernel<T, V, true, false><<<grid, block, 0, st>>>(a, r, ep);   \
+    else if (vec == V)                                                              \
+      absmax_onepass_kernel<T, V, false, false><<<grid, block, 0, st>>>(a, r, ep);  \
+    else                                                                            \
+      absmax_onepass_kernel<T, 1, false, false><<<grid, block, 0, st>>>(a, r, ep);  \
+  } while (0)
+  if (dtype == BVQ_F32)
+    BVQ_ONEPASS(float);
+  else if (dtype == BVQ_BF16)
+    BVQ_ONEPASS(bf16_t);
+  else
+    BVQ_ONEPASS(f16_t);
+#undef BVQ_ONEPASS
+  return check_launch("bvq_absmax_scale_onepass");
+}
+
 extern "C" int bvq_absmax_scale_running(int pre_op, int dtype, const void* x, int64_t outer, int64_t channels,
                                         int64_t inner, void* stat_out, double min_val, int use_min,
                                         double int_threshold, int scale_dtype, void* scale_out, int run_dtype,
@@ -1140,12 +1398,27 @@ extern "C" int bvq_shard_unpack(const double* gathered, int world, int64_t chann
 extern "C" int bvq_scale_from_stat(const float* stat32, int64_t channels, int stat_dtype, void* stat_out,
                                    double min_val, int use_min, double int_threshold, int scale_dtype,
                                    void* scale_out, bvq_stream_t stream) {
+  return bvq_scale_from_stat_running(stat32, channels, stat_dtype, stat_out, min_val, use_min, int_threshold,
+                                     scale_dtype, scale_out, BVQ_F32, nullptr, 0.0, 0, stream);
+}
+
+extern "C" int bvq_scale_from_stat_running(const float* stat32, int64_t channels, int stat_dtype, void* stat_out,
+                                           double min_val, int use_min, double int_threshold, int scale_dtype,
+                                           void* scale_out, int run_dtype, void* running, double momentum,
+                                           int first_batch, bvq_stream_t stream) {
   if (channels < 1 || bad_dtype(stat_dtype) || bad_dtype(scale_dtype) || !stat32 || !stat_out || !scale_out ||
-      !(int_threshold == int_threshold)) {
+      !(int_threshold == int_threshold) || (running && bad_dtype(run_dtype))) {
     set_error("bvq_scale_from_stat: bad argument");
     return BVQ_ERR_INVALID;
   }
   ScaleEpilogue ep = {};
+  if (running) {
+    ep.running = running;
+    ep.run_dtype = run_dtype;
+    ep.first_batch = first_batch;
+    ep.one_minus_m = (float)(1.0 - momentum);
+    ep.momentum = (float)momentum;
+  }
   ep.scale_out = scale_out;
   ep.scale_dtype = scale_dtype;
   ep.use_min = use_min;

@@ -12,6 +12,8 @@
 namespace bvq {
 
 constexpr int kTieCap = 1024;
+// batch-sharded tensors: a shard's claim on a channel's deposit is its rank, or this when it holds no arg-max
+constexpr double kShardNoOwner = 1073741824.0;  // 2^30, above any rank
 
 static inline int64_t tie_info_words(int64_t channels) { return channels > 1 ? channels : 2 + kTieCap; }
 

@@ -200,6 +200,23 @@ int bvq_absmax_scale_running(int pre_op, int dtype, const void* x, int64_t outer
                              void* scale_out, int run_dtype, void* running, double momentum, int first_batch,
                              void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
 
+/* The same statistic (+ optional scale epilogue, + optional running average) in ONE launch, for per-channel
+ * layouts whose rows the row-mapped kernels walk (bvq_absmax_onepass_supported: 1 / 0).  Persistent waves fold their
+ * maxima into a per-channel key word with an atomic max and count the units they covered in a per-channel counter;
+ * the wave whose count completes a channel finishes it (B/core/stats/stats_op.py:129-141 -> stat_out;
+ * B/core/restrict_val.py:22-42 and B/core/quant/int.py:160 -> scale_out; B/core/stats/stats_wrapper.py:61-66 ->
+ * running).  No wave waits for another.  Results are the bits of bvq_absmax_scale[_running] (a max is exact).
+ * stat_dtype: BVQ_F32 (the batch-sharded route all-reduces it) or the dtype of x.  scale_out / running: nullable.
+ * arrive: `arrive_words` >= 2 * channels uint32 words in device memory that are ALL ZERO when the launch starts;
+ *   the finishing waves hand them back as zeros, so a caller keeps ONE such buffer per stream, cleared once when
+ *   it is allocated, and never clears it again (launches on one stream are ordered; do not share it between streams).
+ * BVQ_ERR_UNSUPPORTED: layout not covered (per-tensor, column-mapped): call bvq_absmax_scale[_running]. */
+int bvq_absmax_onepass_supported(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner);
+int bvq_absmax_scale_onepass(int pre_op, int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+                             int stat_dtype, void* stat_out, double min_val, int use_min, double int_threshold,
+                             int scale_dtype, void* scale_out, int run_dtype, void* running, double momentum,
+                             int first_batch, uint32_t* arrive, int64_t arrive_words, bvq_stream_t stream);
+
 /* Running average kept by _RuntimeStats (B/core/stats/stats_wrapper.py:61-66), one launch:
  *   first_batch: running *= stat ; otherwise running *= (1 - momentum); running += momentum * stat
  * with torch's rounding points (in-place results in run_dtype, momentum * stat in stat_dtype). */
@@ -219,6 +236,29 @@ int bvq_running_stats_update(int run_dtype, void* running, int stat_dtype, const
  *   is another shard; per_channel = 0: total_ties[0] = ties over all shards. */
 int bvq_scale_from_stat(const float* stat32, int64_t channels, int stat_dtype, void* stat_out, double min_val,
                         int use_min, double int_threshold, int scale_dtype, void* scale_out, bvq_stream_t stream);
+/* bvq_scale_from_stat with _RuntimeStats' running average folded in (the rounding points of bvq_absmax_scale_running);
+ * running: nullable. */
+int bvq_scale_from_stat_running(const float* stat32, int64_t channels, int stat_dtype, void* stat_out, double min_val,
+                                int use_min, double int_threshold, int scale_dtype, void* scale_out, int run_dtype,
+                                void* running, double momentum, int first_batch, bvq_stream_t stream);
+/* The stats-scaled backward of ONE BATCH SHARD (per-channel layouts of bvq_fakequant_bwd_stats): dx WITHOUT the deposit,
+ * and this shard's message for the backward all-gather, float64 [2][channels]: row 0 = the channel's dscale sum kept
+ * in double (the shards' sums are added in double and rounded to float32 once: bvq_shard_unpack_deposit), row 1 = its
+ * claim on the channel's deposit (`rank`, or 2^30 when no element of the shard attains the statistic); first_pos[c] =
+ * the shard's first arg-max position (outer * inner + i; -1: none).  arrive (nullable): the arrival buffer of
+ * bvq_fakequant_bwd_stats_onepass -- the streaming kernel's last-arriving wave per channel then writes the message
+ * (one launch); without it, or on column-mapped layouts, a one-wave-per-channel launch follows the streaming kernel.
+ * workspace: bvq_fakequant_bwd_stats_workspace_bytes.
+ * bvq_shard_unpack_deposit: from the gathered [world][2][channels] messages, per channel: dscale_total (nullable out)
+ * = the double sum over the shards in rank order, rounded once (the same bits on every rank); on the shard that owns
+ * the deposit (lowest claiming rank) dscale -> statistic's gradient (B/core/quant/int.py:160 backward, rounding points
+ * of bvq_fakequant_bwd_stats) deposited on dx at first_pos[c].  One launch instead of unpack + cast + divide + deposit. */
+int bvq_fakequant_bwd_shard(const bvq_quant_desc* d, const void* g, const void* x, const void* scale, const void* zp,
+                            const void* stat, void* dx, double* message, int64_t* first_pos, int rank, void* workspace,
+                            int64_t workspace_bytes, uint32_t* arrive, int64_t arrive_words, bvq_stream_t stream);
+int bvq_shard_unpack_deposit(int dtype, const void* x, void* dx, const double* gathered, int world, int64_t channels,
+                             int rank, const int64_t* first_pos, int64_t inner, int scale_dtype, double int_threshold,
+                             int quot_dtype, int pre_op, float* dscale_total, bvq_stream_t stream);
 int bvq_shard_pack(const float* dscale, const int64_t* tie_info, int64_t channels, int rank, int per_channel,
                    double* message, bvq_stream_t stream);
 int bvq_shard_unpack(const double* gathered, int world, int64_t channels, int rank, int per_channel,
@@ -475,6 +515,21 @@ int bvq_fakequant_bwd_stats(const bvq_quant_desc* desc, const void* g, const voi
                             const void* zp, const void* stat, void* dx, float* dscale, int scale_dtype,
                             double int_threshold, int quot_dtype, void* workspace, int64_t workspace_bytes,
                             bvq_stream_t stream);
+
+/* bvq_fakequant_bwd_stats in ONE launch (row-mapped per-channel layouts; bvq_fakequant_bwd_stats_onepass_supported:
+ * 1 / 0): the backward kernel writes dx and its per-unit partials through to memory (agent scope), every wave counts
+ * its unit in on its channel's arrival counter, and the wave whose count completes the channel sums the channel's
+ * dscale partials (double, fixed order), takes the first arg-max position, converts dscale into the statistic's
+ * gradient and deposits it on that element of dx -- the finishing launch of bvq_fakequant_bwd_stats, done by whoever
+ * arrives last; no wave waits.  Same results, bit for bit (the sums are taken in a fixed order of their own).
+ * arrive: `arrive_words` >= channels uint32 words, ALL ZERO when the launch starts, handed back as zeros (the
+ * contract of bvq_absmax_scale_onepass; the two may share one buffer on one stream).  workspace: as
+ * bvq_fakequant_bwd_stats_workspace_bytes. */
+int bvq_fakequant_bwd_stats_onepass_supported(const bvq_quant_desc* d);
+int bvq_fakequant_bwd_stats_onepass(const bvq_quant_desc* d, const void* g, const void* x, const void* scale,
+                                    const void* zp, const void* stat, void* dx, float* dscale, int scale_dtype,
+                                    double int_threshold, int quot_dtype, void* workspace, int64_t workspace_bytes,
+                                    uint32_t* arrive, int64_t arrive_words, bvq_stream_t stream);
 
 /* ---- the other quantizers of the family -------------------------------------------
  * BinaryQuant / ClampedBinaryQuant (B/core/quant/binary.py:19-101), TernaryQuant (B/core/quant/ternary.py:18-66),

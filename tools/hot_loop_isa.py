@@ -57,8 +57,9 @@ def classify(op):
 def kernel_body(asm, symbol):
     lines = asm.splitlines()
     start = next(i for i, l in enumerate(lines) if l.startswith(symbol + ':'))
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith('s_endpgm'))
-    return lines[start:end + 1]
+    # (the function's end marker, not its first s_endpgm: the compiler may lay blocks out behind an early exit)
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end'))
+    return lines[start:end]
 
 
 def loops(body):
