@@ -533,12 +533,13 @@ class _SpLike(NamedTuple):
     int_threshold: float
 
 
-def _fast_backward_fallback(xc, scale, zp, stat, int_threshold, dv, qr, shape, gy, gscale):
-    """what the C++ node cannot do itself (a gradient arriving through `scale`, an unaligned or strided gradient)"""
+def _fast_backward_fallback(xc, scale, zp, stat, int_threshold, dv, qr, shape, gy, gscale, group=None):
+    """what the C++ nodes cannot do themselves (a gradient arriving through `scale`, an unaligned or strided gradient,
+    a batch-sharded whole-tensor statistic)"""
     desc = nat.QuantDesc(dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], dv[7], dv[8], qr[0], qr[1], dv[9], dv[10],
                          dv[11], dv[12], dv[13], dv[14])
     sp = _SpLike(dv[0], dv[1], dv[2], qr[3])
-    return stats_backward(xc, scale.view(shape), zp, stat, int_threshold, desc, sp, None, dv[13], None, gy, gscale)
+    return stats_backward(xc, scale.view(shape), zp, stat, int_threshold, desc, sp, group, dv[13], None, gy, gscale)
 
 
 def _fast_module():
@@ -553,7 +554,7 @@ def _fast_module():
                 spec = importlib.util.spec_from_file_location('_bvq_autograd', path)
                 mod = importlib.util.module_from_spec(spec)
                 spec.loader.exec_module(mod)
-                mod.init(nat.LIB_PATH, _fast_backward_fallback)
+                mod.init(nat.LIB_PATH, _fast_backward_fallback)   # raises on another ABI version of libbvq.so
                 _FAST, _FAST_PATH = mod, path
             except Exception:  # noqa: BLE001  (an extension built against another torch: the Python route serves)
                 _FAST = False
@@ -585,3 +586,54 @@ def fast_stats_fakequant(x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste
     return mod.stats_fakequant(x, zp, int_threshold, dv, float(qmin), float(qmax), float(sp.min_val or 0.0),
                                bool(sp.min_val), float(thr_div), float(thr_bwd), float(sp.int_threshold), sdt,
                                list(sp.scaling_shape), nat.stream_ptr(x.device))
+
+
+def fast_act_stats_fakequant(x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, pre_op, group, runtime):
+    """The activation route of StatsFakeQuantFn (statistic kernel + quantizer kernel, the running statistic folded in,
+    optionally batch-sharded with its two collectives) through the C++ node -> (y, scale, stat) with
+    `runtime.bvq_running_folded` set, or None: not a case it covers (channels_last / strided / unaligned input, a sharded
+    whole-tensor statistic, a running buffer that is not a plain [channels] device tensor, no extension built, timers
+    active)."""
+    mod = _fast_module()
+    if not mod or not hasattr(mod, 'act_stats_fakequant') or not x.is_cuda or sp.nhwc or not x.is_contiguous() \
+            or x.dtype not in _FLOATS or not config.FUSED_PATHS or x.numel() == 0:
+        return None
+    timer = nat._timer
+    if timer is not None and getattr(timer, 'enabled', True):
+        return None  # bench.py is bracketing the C-ABI calls of this step with HIP events: keep them visible
+    if x.device.index is not None and x.device.index != torch.cuda.current_device():
+        return None
+    if group is not None and sp.channels <= 1:
+        return None
+    running = None
+    momentum, first = 0.0, False
+    if runtime is not None:
+        buf = runtime.running_stats
+        if not (buf.is_cuda and buf.is_contiguous() and buf.numel() == sp.channels and buf.dtype in _FLOATS):
+            return None
+        running, momentum, first = buf, runtime.momentum, runtime.first_batch
+    if len(sp.scaling_shape) > 0:
+        scale_dtype, thr_div = x.dtype, _as_dtype_value(sp.int_threshold, x.dtype)
+        quot_dtype, thr_bwd = scale_dtype, _as_dtype_value(sp.int_threshold, scale_dtype)
+    else:
+        scale_dtype = torch.promote_types(x.dtype, int_threshold.dtype)
+        thr_div = sp.int_threshold
+        quot_dtype, thr_bwd = torch.promote_types(scale_dtype, int_threshold.dtype), sp.int_threshold
+    if sp.channels > 1 and len(sp.scaling_shape) == 0:
+        return None
+    ct = torch.result_type(x, torch.empty(sp.scaling_shape, dtype=scale_dtype, device='meta'))
+    if ct != x.dtype:
+        return None
+    code, sdt = nat.dtype_code(x.dtype), nat.dtype_code(scale_dtype)
+    zp = _zero_zero_point(x.device)
+    st = nat.stream_ptr(x.device)
+    arrive = nat.arrival_buffer(x.device, st, 2 * sp.channels) if sp.channels > 1 else None
+    dv = (sp.outer, sp.channels, sp.inner, code, code, sdt, nat.dtype_code(zp.dtype), int(sp.channels > 1), 0, round_mode,
+          scalar_mode(), int(clamp_ste), nat.OUT_DEQUANT, pre_op, 0)
+    out = mod.act_stats_fakequant(x, zp, int_threshold, running, arrive, dv, float(qmin), float(qmax),
+                                  float(sp.min_val or 0.0), bool(sp.min_val), float(thr_div), float(thr_bwd),
+                                  float(sp.int_threshold), sdt, nat.dtype_code(quot_dtype), list(sp.scaling_shape), st,
+                                  float(momentum), bool(first), group)
+    if out is not None and runtime is not None:
+        runtime.bvq_running_folded = True
+    return out

@@ -249,6 +249,9 @@ class RescalingIntQuant(torch.nn.Module):
             if runtime is None and group is None:  # a weight: the autograd node in C++ when it is built and applies
                 fast = _fused.fast_stats_fakequant(x, int_threshold, sp, tmpl['qmin'], tmpl['qmax'], tmpl['round_mode'],
                                                    tmpl['clamp_ste'], pre_op)
+            elif config.CPP_AUTOGRAD:              # an activation: statistic kernel + quantizer kernel, same idea
+                fast = _fused.fast_act_stats_fakequant(x, int_threshold, sp, tmpl['qmin'], tmpl['qmax'],
+                                                       tmpl['round_mode'], tmpl['clamp_ste'], pre_op, group, runtime)
             if fast is not None:
                 y, scale, stat = fast
             else:

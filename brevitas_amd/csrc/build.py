@@ -113,8 +113,9 @@ def build_autograd(force=False, verbose=False):
     src = os.path.join(CSRC, 'bvq_autograd.cpp')
     import torch
     h = hashlib.sha256()
-    with open(src, 'rb') as fh:
-        h.update(fh.read())
+    for path in (src, os.path.join(ROOT, 'include', 'bvq.h')):   # the node takes every prototype from the header
+        with open(path, 'rb') as fh:
+            h.update(fh.read())
     h.update(torch.__version__.encode())
     stamp = os.path.join(ROOT, 'build', 'autograd', 'stamp')
     if not force and os.path.exists(AUTOGRAD_SO) and os.path.exists(stamp):
@@ -125,6 +126,7 @@ def build_autograd(force=False, verbose=False):
     bdir = os.path.join(ROOT, 'build', 'autograd')
     os.makedirs(bdir, exist_ok=True)
     cpp_extension.load(name='_bvq_autograd', sources=[src], build_directory=bdir, extra_cflags=['-O2', '-std=c++17'],
+                       extra_include_paths=[os.path.join(ROOT, 'include')],
                        extra_ldflags=['-ldl'], verbose=verbose, is_python_module=False)
     built = os.path.join(bdir, '_bvq_autograd.so')
     shutil.copyfile(built, AUTOGRAD_SO)

@@ -83,3 +83,92 @@ def test_cpp_node_step_captures_into_a_hip_graph():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, want_y) and torch.equal(dx, want_dx)
+
+
+def _act_steps(q, x, g, steps, cases):
+    out = []
+    for _ in range(steps):
+        for c in cases:
+            xi = x.clone().requires_grad_(True)
+            y, scale = q(xi)[:2]
+            gg = g.transpose(0, 1).contiguous().transpose(0, 1) if c.get('strided') else g
+            loss = (y * gg).sum() if c.get('use_y', True) else 0.0
+            if c.get('h') is not None:
+                loss = loss + (scale.reshape(-1).float() * c['h'][:scale.numel()]).sum()
+            loss.backward()
+            out.append((y.detach().clone(), scale.detach().clone(), xi.grad.detach().clone(),
+                        q.scaling_impl.runtime_stats.running_stats.detach().clone()))
+    return out
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16], ids=['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('per_channel', [True, False], ids=['per_channel', 'per_tensor'])
+@pytest.mark.parametrize('shape', [(24, 48, 28, 28), (6, 10, 56, 56), (4, 16, 7, 9)], ids=lambda s: 'x'.join(map(str, s)))
+def test_cpp_activation_node_equals_python_function(dtype, per_channel, shape, monkeypatch):
+    """the stats-scaled ACTIVATION quantizer (statistic kernel + quantizer kernel, running statistic folded in) through
+    the C++ node against the Python Function: y, scale, dx and the running statistic bit for bit over several steps, on
+    the direct route and on what the node hands back (gradient through `scale`, strided gradient, only `scale` used)"""
+    from bench import build_quantizer
+    from brevitas_amd.core.quant import _fused
+    assert _fused._fast_module(), 'brevitas_amd/_bvq_autograd.so is not built'
+    torch.manual_seed(123456)
+    x = torch.randn(shape, device=DEV).to(dtype)
+    g = torch.randn(shape, device=DEV).to(dtype)
+    h = torch.randn(shape[1], device=DEV)
+    cases = [dict(), dict(h=h), dict(strided=True), dict(h=h, use_y=False)]
+    calls = {'n': 0}
+    real = _fused.fast_act_stats_fakequant
+
+    def counted(*a, **k):
+        r = real(*a, **k)
+        calls['n'] += r is not None
+        return r
+    monkeypatch.setattr(_fused, 'fast_act_stats_fakequant', counted)
+    fast = _act_steps(build_quantizer(shape[1], per_channel, torch.device(DEV)), x, g, 2, cases)
+    assert calls['n'] == 2 * len(cases), 'the C++ node did not take these steps'
+    monkeypatch.setattr(_fused, 'fast_act_stats_fakequant', lambda *a, **k: None)
+    slow = _act_steps(build_quantizer(shape[1], per_channel, torch.device(DEV)), x, g, 2, cases)
+    for i, (a, b) in enumerate(zip(fast, slow)):
+        for ta, tb, what in zip(a, b, ('y', 'scale', 'dx', 'running')):
+            assert torch.equal(_bits(ta), _bits(tb)), (i, what)
+
+
+def test_cpp_activation_node_sharded_world_of_one(monkeypatch):
+    """the batch-sharded branch of the node (float32 statistic, all-reduce, scale launch, message, all-gather,
+    unpack + deposit) with a one-rank group: equals the unsharded quantizer bit for bit"""
+    import torch.distributed as dist
+    from bench import build_quantizer
+    from brevitas_amd.core.quant import _fused
+    import os
+    import socket
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
+    sock.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        _sharded_world_of_one(monkeypatch, dist, build_quantizer, _fused)
+    finally:
+        dist.destroy_process_group()
+
+
+def _sharded_world_of_one(monkeypatch, dist, build_quantizer, _fused):
+    torch.manual_seed(5)
+    x = torch.randn(8, 32, 28, 28, device=DEV, dtype=torch.bfloat16)
+    g = torch.randn_like(x)
+    calls = {'n': 0}
+    real = _fused.fast_act_stats_fakequant
+
+    def counted(*a, **k):
+        r = real(*a, **k)
+        calls['n'] += r is not None
+        return r
+    monkeypatch.setattr(_fused, 'fast_act_stats_fakequant', counted)
+    sharded = _act_steps(build_quantizer(32, True, torch.device(DEV), dist.group.WORLD), x, g, 2, [dict()])
+    plain = _act_steps(build_quantizer(32, True, torch.device(DEV)), x, g, 2, [dict()])
+    assert calls['n'] == 4
+    for a, b in zip(sharded, plain):
+        for ta, tb, what in zip(a, b, ('y', 'scale', 'dx', 'running')):
+            assert torch.equal(_bits(ta), _bits(tb)), what

@@ -26,17 +26,33 @@ def _bits(t):
     return t.detach().contiguous().view(torch.int16 if t.element_size() == 2 else torch.int32)
 
 
-def _check_dx(got, want, max_deposits, dtype, what):
-    """dx of a shard against the slice of the full-batch dx: bit-exact except at the elements that receive a statistic's
-    gradient -- the shards' scale-gradient sums are rounded before they are added, the full batch rounds once -- and at
-    most `max_deposits` of those over BOTH shards (a deposit lands on exactly one of them)"""
-    diff = (_bits(got) != _bits(want)).nonzero()
-    ndiff = torch.tensor([diff.shape[0]])
+def _check_dx(got, want, x_shard, g_shard, g_full, stat, per_channel, max_ulp, what):
+    """dx of a shard against the slice of the full-batch dx: bit-exact everywhere except at elements that RECEIVE the
+    statistic's gradient, i.e. elements attaining the statistic (|x| == stat of their channel).  There both runs add
+    float32 partial sums of the scale gradient in double -- since round 3 the shards' sums are no longer rounded to
+    float32 before they are added -- but the partials themselves come from different unit decompositions (8 rows vs 4
+    rows per channel), and a float32 partial carries an error of one unit in the last place of the MAGNITUDES it
+    summed (sum |g| over the channel, / int_threshold once it is the statistic's gradient).  So the two dx values
+    differ by at most `max_ulp` units in the last place of max(deposited term, that magnitude); the term is read off
+    want - g (dx = own + term with own ~ g).  (Round 2 tolerated 5 % of the largest |dx| and never looked at the
+    positions.)"""
+    diff = _bits(got) != _bits(want)
+    ax = x_shard.detach().abs()
+    st = stat.detach().to(ax.dtype)
+    attains = ax == (st.reshape(1, -1, 1, 1) if per_channel else st.reshape(()))
+    assert not bool((diff & ~attains).any()), (what, 'a differing element does not attain the statistic')
+    if bool(diff.any()):
+        summed = g_full.double().abs().sum(dim=(0, 2, 3) if per_channel else None) / 128.0
+        summed = (summed.reshape(1, -1, 1, 1) if per_channel else summed.reshape(1, 1, 1, 1)).expand_as(got)[diff]
+        gd, wd, og = got[diff].double(), want[diff].double(), g_shard[diff].double()
+        mag = torch.maximum(torch.maximum(gd.abs(), wd.abs()), torch.maximum((wd - og).abs(), summed))
+        mant = 7 if got.dtype == torch.bfloat16 else 23
+        ulp = torch.exp2(torch.floor(torch.log2(mag)) - mant)
+        worst = float(((gd - wd).abs() / ulp).max())
+        assert worst <= max_ulp, (what, 'ulps between the two runs at a deposit', worst)
+    ndiff = torch.tensor([int(diff.sum())])
     dist.all_reduce(ndiff)
-    assert int(ndiff) <= max_deposits, (what, 'differing elements over both shards', int(ndiff))
-    tol = 0.05 if dtype == torch.bfloat16 else 1e-4
-    g, w = got.float(), want.float()
-    assert torch.allclose(g, w, rtol=tol, atol=tol * float(w.abs().max())), what
+    return int(ndiff)
 
 
 def _worker(rank, world, port, q):
@@ -77,7 +93,10 @@ def _worker(rank, world, port, q):
                 lo, hi = rank * per, (rank + 1) * per
                 assert torch.equal(_bits(scale), _bits(scalef)), ('scale', dtype, per_channel)
                 assert torch.equal(_bits(y), _bits(yf[lo:hi])), ('y', dtype, per_channel)
-                _check_dx(xs.grad, xf.grad[lo:hi], c if per_channel else 1, dtype, ('dx', dtype, per_channel))
+                stat = scalef.float() * 128.0   # the statistic itself (powers of two scale exactly)
+                nd = _check_dx(xs.grad, xf.grad[lo:hi], xs, g[lo:hi].to(dev), g.to(dev), stat, per_channel, 1 if dtype == torch.bfloat16 else 4,
+                               ('dx', dtype, per_channel))
+                assert nd <= (c if per_channel else 1), ('deposits that differ', nd)
                 assert torch.equal(_bits(qs.scaling_impl.runtime_stats.running_stats),
                                    _bits(qf.scaling_impl.runtime_stats.running_stats)), ('running', dtype, per_channel)
             # the default activation quantizer: percentile statistic (sharded radix select, 15-bit first digit) over its
@@ -98,7 +117,11 @@ def _worker(rank, world, port, q):
                 torch.cuda.synchronize()
                 assert torch.equal(_bits(sa), _bits(sb)), ('percentile scale', dtype, step)
                 assert torch.equal(_bits(yb), _bits(ya[rank * 4:(rank + 1) * 4])), ('percentile y', dtype, step)
-                _check_dx(xs.grad, xf.grad[rank * 4:(rank + 1) * 4], 1, dtype, ('percentile dx', dtype, step))
+                # collection steps: the k-th value's gradient lands on the element(s) holding it; afterwards the scale
+                # is a learned parameter and dx must be bit-identical
+                nd = _check_dx(xs.grad, xf.grad[rank * 4:(rank + 1) * 4], xs, g[rank * 4:(rank + 1) * 4].to(dev), g.to(dev), sa.float() * 128.0, False,
+                               1 if dtype == torch.bfloat16 else 4, ('percentile dx', dtype, step))
+                assert nd <= (1 if step < 2 else 0), ('percentile deposits that differ', step, nd)
         q.put((rank, 'ok'))
     except Exception:  # noqa: BLE001
         import traceback
