@@ -16,7 +16,7 @@ import torch
 from brevitas_amd.core.quant.int import RescalingIntQuant
 from brevitas_amd.proxy import FusedActivationQuantProxy
 
-__all__ = ['calibration_mode', 'finalize_collect_stats', 'DisableEnableQuantization']
+__all__ = ['calibration_mode', 'bias_correction_mode', 'finalize_collect_stats', 'DisableEnableQuantization']
 
 
 def finalize_collect_stats(module):
@@ -108,4 +108,73 @@ class calibration_mode:
         self.model.apply(finalize_collect_stats)
         self.disable_quant_inference.apply(self.model, is_training=self.previous_training_state,
                                            quantization_enabled=True)
+        return False
+
+
+class bias_correction_mode:
+    """with bias_correction_mode(model): model(batch) ...   (B/graph/calibrate.py:68-80,166-276)
+
+    Every quantized conv / linear layer is run twice more per call: once with its quantizers off and once with them on
+    (plain `forward`, so hooks of the caller fire once per call); the difference of the two outputs' per-channel means
+    is accumulated, and the layer hands on its quantized output PLUS that difference -- the next layer sees what
+    the float layer would have produced on average.  On exit each layer's bias receives the mean difference over the
+    calls (a bias parameter is created where the layer had none)."""
+
+    def __init__(self, model: torch.nn.Module, enabled: bool = True):
+        self.model = model
+        self.enabled = enabled
+        self.hooks = []
+        self.iterations = {}
+        self.correction_map = {}
+
+    @staticmethod
+    def _channel_dim(t, module):
+        return 2 if t.dim() == 3 and isinstance(module, torch.nn.Linear) else 1   # B/graph/calibrate.py:183-188
+
+    @staticmethod
+    def _channel_mean(t, dim):
+        t = t.transpose(0, dim)
+        return t.reshape(t.shape[0], -1).mean(dim=1).detach()                     # compute_mean, :179-181
+
+    def _hook(self, module, inp, output, name):
+        saved = (getattr(module, 'bvq_disable_weight_quant', False), getattr(module, 'bvq_disable_input_quant', False))
+        module.bvq_disable_weight_quant = module.bvq_disable_input_quant = True
+        try:
+            float_out = module.forward(*inp)        # forward, not __call__: no recursion into this hook
+        finally:
+            module.bvq_disable_weight_quant, module.bvq_disable_input_quant = saved
+        quant_out = module.forward(*inp)
+        dim = self._channel_dim(quant_out, module)
+        error = self._channel_mean(float_out, dim) - self._channel_mean(quant_out, dim)
+        if name in self.correction_map:
+            self.correction_map[name] += error
+        else:
+            self.correction_map[name] = error
+        self.iterations[name] += 1
+        shape = [1] * quant_out.dim()
+        shape[dim] = -1
+        return quant_out + error.reshape(shape)
+
+    def __enter__(self):
+        if self.enabled:
+            from functools import partial
+
+            from brevitas_amd.nn import _QuantWeightMixin
+            for name, module in self.model.named_modules():
+                if isinstance(module, _QuantWeightMixin):
+                    self.iterations[name] = 0
+                    self.hooks.append(module.register_forward_hook(partial(self._hook, name=name)))
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        for name, module in self.model.named_modules():
+            if name in self.correction_map:
+                correction = self.correction_map[name] / self.iterations[name]
+                if module.bias is not None:
+                    module.bias.data += correction
+                else:
+                    module.register_parameter('bias', torch.nn.Parameter(correction).to(module.weight.device))
+        for hook in self.hooks:
+            hook.remove()
+        self.hooks = []
         return False

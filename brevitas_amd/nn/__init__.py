@@ -31,7 +31,7 @@ class _QuantWeightMixin:
     def _quant_all(self, x):
         """-> (x, w, bias) as the float op consumes them (B/nn/quant_layer.py:302-333)"""
         in_scale = None
-        if self.input_quant is not None:
+        if self.input_quant is not None and not getattr(self, 'bvq_disable_input_quant', False):  # bias correction
             x, in_scale, _, _ = self.input_quant(x)
         w, w_scale, _, _ = self.quant_weight()
         bias = self.bias
