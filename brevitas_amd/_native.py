@@ -335,10 +335,10 @@ def stats(kind, x, outer, channels, inner, out_f32=False, pre_op=PRE_NONE):
     dt = dtype_code(x.dtype)
     nout = channels * (2 if kind == STAT_MINMAX else 1)
     out = torch.empty(nout, dtype=torch.float32 if out_f32 else x.dtype, device=dev)
-    if kind == STAT_ABSMAX and channels > 1 and lib.bvq_absmax_onepass_supported(dt, ptr(x), outer, channels, inner):
+    if kind == STAT_ABSMAX and lib.bvq_absmax_onepass_supported(dt, ptr(x), outer, channels, inner):
         with _DeviceGuard(dev):
             st = stream_ptr(dev)
-            arrive = arrival_buffer(dev, st, 2 * channels)
+            arrive = arrival_buffer(dev, st, max(2 * channels, 18))
             if arrive is not None:
                 if _timer is not None:
                     _timer.before('bvq_stats')
@@ -432,11 +432,11 @@ def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype,
     dt = dtype_code(x.dtype)
     stat = torch.empty(channels, dtype=x.dtype, device=dev)
     scale = torch.empty(channels, dtype=scale_dtype, device=dev)
-    if channels > 1 and lib.bvq_absmax_onepass_supported(dt, ptr(x), outer, channels, inner):
+    if lib.bvq_absmax_onepass_supported(dt, ptr(x), outer, channels, inner):
         # one launch: the statistic kernel's last-arriving wave per channel finishes it
         with _DeviceGuard(dev):
             st = stream_ptr(dev)
-            arrive = arrival_buffer(dev, st, 2 * channels)
+            arrive = arrival_buffer(dev, st, max(2 * channels, 18))
             if arrive is not None:
                 if _timer is not None:
                     _timer.before('bvq_stats')

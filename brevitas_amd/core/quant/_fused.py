@@ -583,9 +583,11 @@ def fast_stats_fakequant(x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste
     dv = (sp.outer, sp.channels, sp.inner, code, code, sdt, nat.dtype_code(zp.dtype), 1, 0, round_mode, scalar_mode(),
           int(clamp_ste), nat.OUT_DEQUANT, pre_op, 0)
     thr_bwd = _as_dtype_value(sp.int_threshold, scale_dtype)
-    return mod.stats_fakequant(x, zp, int_threshold, dv, float(qmin), float(qmax), float(sp.min_val or 0.0),
+    st = nat.stream_ptr(x.device)
+    arrive = nat.arrival_buffer(x.device, st, sp.channels) if nat.ONEPASS_BWD else None
+    return mod.stats_fakequant(x, zp, int_threshold, arrive, dv, float(qmin), float(qmax), float(sp.min_val or 0.0),
                                bool(sp.min_val), float(thr_div), float(thr_bwd), float(sp.int_threshold), sdt,
-                               list(sp.scaling_shape), nat.stream_ptr(x.device))
+                               list(sp.scaling_shape), st)
 
 
 def fast_act_stats_fakequant(x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, pre_op, group, runtime):
@@ -627,7 +629,7 @@ def fast_act_stats_fakequant(x, int_threshold, sp, qmin, qmax, round_mode, clamp
     code, sdt = nat.dtype_code(x.dtype), nat.dtype_code(scale_dtype)
     zp = _zero_zero_point(x.device)
     st = nat.stream_ptr(x.device)
-    arrive = nat.arrival_buffer(x.device, st, 2 * sp.channels) if sp.channels > 1 else None
+    arrive = nat.arrival_buffer(x.device, st, max(2 * sp.channels, 18))
     dv = (sp.outer, sp.channels, sp.inner, code, code, sdt, nat.dtype_code(zp.dtype), int(sp.channels > 1), 0, round_mode,
           scalar_mode(), int(clamp_ste), nat.OUT_DEQUANT, pre_op, 0)
     out = mod.act_stats_fakequant(x, zp, int_threshold, running, arrive, dv, float(qmin), float(qmax),

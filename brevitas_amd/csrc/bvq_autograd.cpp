@@ -158,9 +158,10 @@ torch::autograd::variable_list python_backward(torch::autograd::AutogradContext*
 // ---- weights: one-launch forward ------------------------------------------------------------------------------------
 class StatsFakeQuant : public torch::autograd::Function<StatsFakeQuant> {
  public:
+  // arrive: the stream's arrival buffer (an EMPTY tensor when absent)
   static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x,
-                                                const at::Tensor& zp, const at::Tensor& int_threshold, int64_t wsb,
-                                                const Params& p) {
+                                                const at::Tensor& zp, const at::Tensor& int_threshold,
+                                                const at::Tensor& arrive, int64_t wsb, const Params& p) {
     ctx->set_materialize_grads(false);
     const int64_t ch = p.d.channels;
     at::Tensor y = at::empty_like(x);
@@ -171,7 +172,7 @@ class StatsFakeQuant : public torch::autograd::Function<StatsFakeQuant> {
                                     scale.data_ptr(), y.data_ptr(), ws.data_ptr(), wsb,
                                     reinterpret_cast<void*>(p.stream)),
           "bvq_stats_fakequant_fwd");
-    ctx->save_for_backward({x, scale, zp, stat, int_threshold});
+    ctx->save_for_backward({x, scale, zp, stat, int_threshold, arrive});
     ctx->saved_data["desc"] = desc_ints(p);
     ctx->saved_data["qrange"] = std::vector<double>{p.d.qmin, p.d.qmax, p.thr_bwd, p.thr_raw};
     ctx->saved_data["shape"] = p.shape;
@@ -183,10 +184,10 @@ class StatsFakeQuant : public torch::autograd::Function<StatsFakeQuant> {
   static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
                                                  torch::autograd::variable_list grads) {
     const auto saved = ctx->get_saved_variables();
-    const at::Tensor &x = saved[0], &scale = saved[1], &zp = saved[2], &stat = saved[3];
+    const at::Tensor &x = saved[0], &scale = saved[1], &zp = saved[2], &stat = saved[3], &arrive = saved[5];
     const at::Tensor& gy = grads[0];
     const at::Tensor& gscale = grads[1];
-    if (!direct_gradient(gy, gscale, x)) return python_backward(ctx, gy, gscale, nullptr, 5);
+    if (!direct_gradient(gy, gscale, x)) return python_backward(ctx, gy, gscale, nullptr, 6);
     const auto dv = ctx->saved_data["desc"].toIntVector();
     const auto qr = ctx->saved_data["qrange"].toDoubleVector();
     const bvq_quant_desc d = desc_from(dv, qr);
@@ -196,11 +197,22 @@ class StatsFakeQuant : public torch::autograd::Function<StatsFakeQuant> {
     at::Tensor ds = at::empty({d.channels}, x.options().dtype(at::kFloat));
     at::Tensor ws = at::empty({wsb}, x.options().dtype(at::kByte));
     const int sdt = (int)dv[15];
-    check(p_bvq_fakequant_bwd_stats(&d, gy.data_ptr(), x.data_ptr(), scale.data_ptr(), zp.data_ptr(), stat.data_ptr(),
-                                    dx.data_ptr(), ds.data_ptr<float>(), sdt, qr[2], sdt, ws.data_ptr(), wsb,
-                                    reinterpret_cast<void*>(dv[16])),
-          "bvq_fakequant_bwd_stats");
-    return {dx, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    void* st = reinterpret_cast<void*>(dv[16]);
+    if (arrive.numel() >= d.channels && p_bvq_fakequant_bwd_stats_onepass_supported(&d)) {
+      // one launch: the backward kernel's last-arriving wave per channel sums, converts and deposits
+      check(p_bvq_fakequant_bwd_stats_onepass(&d, gy.data_ptr(), x.data_ptr(), scale.data_ptr(), zp.data_ptr(),
+                                              stat.data_ptr(), dx.data_ptr(), ds.data_ptr<float>(), sdt, qr[2], sdt,
+                                              ws.data_ptr(), wsb, reinterpret_cast<uint32_t*>(arrive.data_ptr()),
+                                              arrive.numel(), st),
+            "bvq_fakequant_bwd_stats_onepass");
+    } else {
+      check(p_bvq_fakequant_bwd_stats(&d, gy.data_ptr(), x.data_ptr(), scale.data_ptr(), zp.data_ptr(), stat.data_ptr(),
+                                      dx.data_ptr(), ds.data_ptr<float>(), sdt, qr[2], sdt, ws.data_ptr(), wsb, st),
+            "bvq_fakequant_bwd_stats");
+    }
+    torch::autograd::variable_list out(6);
+    out[0] = dx;
+    return out;
   }
 };
 
@@ -224,7 +236,7 @@ class ActStatsFakeQuant : public torch::autograd::Function<ActStatsFakeQuant> {
     const bool has_running = running.numel() > 0, has_arrive = arrive.numel() > 0;
     void* run_ptr = has_running ? running.data_ptr() : nullptr;
     const int run_dt = has_running ? code_of(running.scalar_type()) : BVQ_F32;
-    const bool onepass = has_arrive && ch > 1 &&
+    const bool onepass = has_arrive &&
                          p_bvq_absmax_onepass_supported(d.x_dtype, x.data_ptr(), d.outer, ch, d.inner);
     if (onepass) {
       check(p_bvq_absmax_scale_onepass(d.pre_op, d.x_dtype, x.data_ptr(), d.outer, ch, d.inner,
@@ -405,7 +417,8 @@ int abi_version() { return BVQ_ABI_VERSION; }
 // -> (y, scale, stat), or None when the one-launch forward / two-launch backward do not cover this layout
 // desc: the 15 integer fields of bvq_quant_desc in order (qmin / qmax as floats)
 py::object stats_fakequant(const at::Tensor& x, const at::Tensor& zp, const at::Tensor& int_threshold,
-                           const std::vector<int64_t>& di, double qmin, double qmax, double min_val, bool has_min,
+                           const py::object& arrive, const std::vector<int64_t>& di, double qmin, double qmax,
+                           double min_val, bool has_min,
                            double thr_fwd, double thr_bwd, double thr_raw, int64_t scale_dtype,
                            std::vector<int64_t> shape, int64_t stream) {
   Params p = make_params(di, qmin, qmax, min_val, has_min, thr_fwd, thr_bwd, thr_raw, scale_dtype, std::move(shape), stream);
@@ -413,7 +426,8 @@ py::object stats_fakequant(const at::Tensor& x, const at::Tensor& zp, const at::
   // coverage: both workspace queries are host-side and cheap (y's address only matters for its alignment: x's stands in)
   const int64_t wsb = p_bvq_stats_fakequant_fwd_workspace_bytes(&p.d, x.data_ptr(), x.data_ptr());
   if (wsb <= 0 || p_bvq_fakequant_bwd_stats_workspace_bytes(&p.d) <= 0) return py::none();
-  auto out = StatsFakeQuant::apply(x, zp, int_threshold, wsb, p);
+  at::Tensor arr_t = arrive.is_none() ? at::empty({0}, x.options().dtype(at::kInt)) : arrive.cast<at::Tensor>();
+  auto out = StatsFakeQuant::apply(x, zp, int_threshold, arr_t, wsb, p);
   return py::make_tuple(out[0], out[1], out[2]);
 }
 

@@ -68,7 +68,7 @@ struct QuantArgs {
 #define BVQ_F16_BWD_PIPE 1
 #endif
 #ifndef BVQ_F16_COLS_DIV   // the column-mapped kernels' float16 division, same choice
-#define BVQ_F16_COLS_DIV 0
+#define BVQ_F16_COLS_DIV 1
 #endif
 #ifndef BVQ_BWD_DEPTH
 #define BVQ_BWD_DEPTH 4

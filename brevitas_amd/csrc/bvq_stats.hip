@@ -514,20 +514,26 @@ struct ArriveArgs {
   uint32_t per_channel;  // units of one channel
   void* stat_out;
   int32_t stat_dtype, in_dtype;
+  uint32_t* part;        // non-null: no arrival, the unit's maximum goes to part[unit] (a finishing launch follows)
 };
 
-__device__ __forceinline__ void absmax_arrive(const ArriveArgs& r, const ScaleEpilogue& ep, int32_t c, uint32_t m,
-                                              uint32_t n, int lane) {
-  m = wave_max_u32(m);
-  if (lane != 0) return;
-  const uint32_t seen = __hip_atomic_fetch_max(r.key + c, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// one arrival: fold m into *key, then count n in; true (with the group's maximum in `out`, both words handed back as
+// zeros) for the arrival that completes `expected`
+__device__ __forceinline__ bool arrive_max(uint32_t* key, uint32_t* cnt, uint32_t m, uint32_t n, uint32_t expected,
+                                           uint32_t& out) {
+  const uint32_t seen = __hip_atomic_fetch_max(key, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t add = n;
   asm volatile("" : "+v"(add) : "v"(seen));  // the count is added only after the max has been performed (returned)
-  const uint32_t before = __hip_atomic_fetch_add(r.cnt + c, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (before + add != r.per_channel) return;
-  // last arriver of channel c: every other wave's max was performed before its add, and all adds before this one
-  const uint32_t bits = __hip_atomic_exchange(r.key + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(r.cnt + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t before = __hip_atomic_fetch_add(cnt, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (before + add != expected) return false;
+  // last arriver: every other arrival's max was performed before its add, and all adds before this one
+  out = __hip_atomic_exchange(key, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+// statistic, scale epilogue, running statistic of channel c from the key `bits` (what stat_finish_kernel does)
+__device__ __forceinline__ void absmax_finish(const ArriveArgs& r, const ScaleEpilogue& ep, int32_t c, uint32_t bits) {
   const float v = r.in_dtype == BVQ_F16 ? (float)__builtin_bit_cast(f16_t, (uint16_t)bits)
                                          : __builtin_bit_cast(float, bits);
   store_stat(r.stat_out, r.stat_dtype, c, v);
@@ -542,6 +548,15 @@ __device__ __forceinline__ void absmax_arrive(const ArriveArgs& r, const ScaleEp
   }
 }
 
+// per-channel layouts: every wave arrives for itself (m: the lanes' maxima of the wave's unit)
+__device__ __forceinline__ void absmax_arrive(const ArriveArgs& r, const ScaleEpilogue& ep, int32_t c, uint32_t m,
+                                              uint32_t n, int lane) {
+  m = wave_max_u32(m);
+  if (lane != 0) return;
+  uint32_t bits;
+  if (arrive_max(r.key + c, r.cnt + c, m, n, r.per_channel, bits)) absmax_finish(r, ep, c, bits);
+}
+
 // One LONG unit per wave (onepass_tiling: ~8192 waves per launch, each walking tens of rows of its channel), walked as a
 // software pipeline: kOnepassDepth 16-byte chunks per lane are always in flight, the load of chunk i + depth is issued
 // as chunk i is folded into the running maximum.  Buffer loads with an out-of-range offset for the lanes past the
@@ -553,11 +568,9 @@ __device__ __forceinline__ void absmax_arrive(const ArriveArgs& r, const ScaleEp
 //  spills and crawls: profiles/r03_onepass.txt)
 constexpr int kOnepassDepth = 4;
 
+// the lanes' maxima of |x| (as abs_bits<> keys) over one unit
 template <typename T, int VEC, bool NT, bool RELU>
-__global__ __launch_bounds__(kBlock) void absmax_onepass_kernel(StatArgs a, ArriveArgs r, ScaleEpilogue ep) {
-  const Unit u = locate_unit(a.t);
-  if (!u.valid) return;
-  const int lane = threadIdx.x & 63;
+__device__ __forceinline__ uint32_t onepass_unit_max(const StatArgs& a, const Unit& u, int lane) {
   const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + u.base;
   const int64_t extent = (int64_t)(u.nrows - 1) * u.row_stride + u.len;
   const buf_t bx = make_buf(xp, (uint32_t)(extent * (int64_t)sizeof(T)));
@@ -613,6 +626,20 @@ __global__ __launch_bounds__(kBlock) void absmax_onepass_kernel(StatArgs a, Arri
     const int32_t tr = e / tail, k = e - tr * tail;
     const uint32_t b = pre_abs_bits<T, RELU>(xp[(int64_t)tr * u.row_stride + (int64_t)cur.cpr * VEC + k]);
     m = b > m ? b : m;
+  }
+  return m;
+}
+
+template <typename T, int VEC, bool NT, bool RELU>
+__global__ __launch_bounds__(kBlock) void absmax_onepass_kernel(StatArgs a, ArriveArgs r, ScaleEpilogue ep) {
+  const Unit u = locate_unit(a.t);
+  if (!u.valid) return;
+  const int lane = threadIdx.x & 63;
+  uint32_t m = onepass_unit_max<T, VEC, NT, RELU>(a, u, lane);
+  if (r.part) {  // (wave-uniform) whole-tensor statistic: ONE finishing launch over <= 4096 long units follows
+    m = wave_max_u32(m);
+    if (lane == 0) r.part[u.id] = m;
+    return;
   }
   absmax_arrive(r, ep, u.channel, m, 1u, lane);
 }
@@ -1035,6 +1062,19 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
 #ifdef BVQ_CACHE_EXPERIMENT
   if (getenv("BVQ_X_STAT_REV")) a.t.reverse = atoi(getenv("BVQ_X_STAT_REV"));
 #endif
+  // A whole-tensor abs-max as long units: at most kFinishSlice pieces, each walked by one wave of the software-pipelined
+  // kernel of the one-launch route -- the partials then fit ONE finishing launch (the short-unit tiling leaves ~10^4-10^5
+  // partials and needs two): [8192,8192] bf16 34 -> 26 us, profiles/r03_onepass.txt section 5.
+  const bool long_units = kind == BVQ_STAT_ABSMAX && channels == 1 && vec == 16 / dtype_size(dtype) &&
+                          a.t.units > kFinishSlice;
+  if (long_units) {
+    const int64_t quantum = (int64_t)kWave * vec;
+    int64_t piece = (a.t.row_len + kFinishSlice - 1) / kFinishSlice;
+    piece = ((piece + quantum - 1) / quantum) * quantum;
+    a.t.piece_len = piece;
+    a.t.ppr = (a.t.row_len + piece - 1) / piece;
+    a.t.units = a.t.nob * channels * a.t.ppr;
+  }
   const int32_t splits = finish_splits(a.t.nob * a.t.ppr);
   const int64_t mid_words = splits > 1 ? channels * (int64_t)splits : 0;
   const int64_t need = 2 * (a.t.units + mid_words) * (int64_t)sizeof(uint32_t);
@@ -1045,7 +1085,30 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
   a.x = x;
   a.part_a = reinterpret_cast<uint32_t*>(workspace);
   a.part_b = a.part_a + a.t.units;
-  if (dtype == BVQ_F32)
+  if (long_units && cap_unit_extent(a.t, dtype_size(dtype))) {
+    ArriveArgs r = {};
+    r.part = a.part_a;
+    const ScaleEpilogue no_ep = {};
+    const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
+    const bool relu = pre_op == BVQ_PRE_RELU;
+#define BVQ_LONG(T)                                                                           \
+  do {                                                                                        \
+    constexpr int V = elem<T>::vec;                                                           \
+    if (relu)                                                                                 \
+      absmax_onepass_kernel<T, V, false, true><<<grid, block, 0, st>>>(a, r, no_ep);          \
+    else if (nt)                                                                              \
+      absmax_onepass_kernel<T, V, true, false><<<grid, block, 0, st>>>(a, r, no_ep);          \
+    else                                                                                      \
+      absmax_onepass_kernel<T, V, false, false><<<grid, block, 0, st>>>(a, r, no_ep);         \
+  } while (0)
+    if (dtype == BVQ_F32)
+      BVQ_LONG(float);
+    else if (dtype == BVQ_BF16)
+      BVQ_LONG(bf16_t);
+    else
+      BVQ_LONG(f16_t);
+#undef BVQ_LONG
+  } else if (dtype == BVQ_F32)
     launch_stat<float>(kind, pre_op, a, vec, nt, st);
   else if (dtype == BVQ_BF16)
     launch_stat<bf16_t>(kind, pre_op, a, vec, nt, st);
@@ -1146,10 +1209,15 @@ static bool onepass_tiling(int dtype, const void* x, int64_t outer, int64_t chan
 }
 
 static bool onepass_layout(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner) {
+  // (a whole-tensor statistic keeps the two-launch route: thousands of arrivals at one word -- ~80 ns each when they
+  //  come together -- cost more than its two finishing launches, profiles/r03_onepass.txt section 4)
   if (channels < 2 || outer < 1 || inner < 1) return false;
   if ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && cols_plan(dtype, outer, channels, inner).ok) return false;
   return true;
 }
+// arrivals at one channel's words: beyond this the atomics on one address serialise into microseconds
+constexpr int64_t kMaxArrivalsPerChannel = 512;
+static inline int64_t onepass_arrive_words(int64_t channels) { return 2 * channels; }
 
 extern "C" int bvq_absmax_onepass_supported(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner) {
   if (bad_dtype(dtype)) return 0;
@@ -1157,6 +1225,7 @@ extern "C" int bvq_absmax_onepass_supported(int dtype, const void* x, int64_t ou
   int vec;
   Tiling t;
   if (!onepass_tiling(dtype, x, outer, channels, inner, t, vec)) return 0;
+  if (channels > 1 && t.nob * t.ppr > kMaxArrivalsPerChannel) return 0;  // few channels, many units each: two launches
   return t.nob * t.ppr < ((int64_t)1 << 31) ? 1 : 0;
 }
 
@@ -1186,9 +1255,9 @@ extern "C" int bvq_absmax_scale_onepass(int pre_op, int dtype, const void* x, in
     set_error("bvq_absmax_scale_onepass: layout not covered (per-tensor or column-mapped): use bvq_absmax_scale");
     return BVQ_ERR_UNSUPPORTED;
   }
-  if (arrive_words < 2 * channels) {
+  if (arrive_words < onepass_arrive_words(channels)) {
     set_error("bvq_absmax_scale_onepass: arrival buffer of %lld words, %lld needed", (long long)arrive_words,
-              (long long)(2 * channels));
+              (long long)onepass_arrive_words(channels));
     return BVQ_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -1205,6 +1274,8 @@ extern "C" int bvq_absmax_scale_onepass(int pre_op, int dtype, const void* x, in
   r.stat_out = stat_out;
   r.stat_dtype = stat_dtype;
   r.in_dtype = dtype;
+  r.part = nullptr;
+  const unsigned blocks = grid_for_units(a.t.units);
   ScaleEpilogue ep = {};
   if (scale_out) {
     ep.scale_out = scale_out;
@@ -1221,7 +1292,7 @@ extern "C" int bvq_absmax_scale_onepass(int pre_op, int dtype, const void* x, in
     ep.one_minus_m = (float)(1.0 - momentum);
     ep.momentum = (float)momentum;
   }
-  const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
+  const dim3 grid(blocks), block(kBlock);
   const bool relu = pre_op == BVQ_PRE_RELU;
 #define BVQ_ONEPASS(T)                                                              \
   do {                                                                              \

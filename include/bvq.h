@@ -207,6 +207,8 @@ int bvq_absmax_scale_running(int pre_op, int dtype, const void* x, int64_t outer
  * B/core/restrict_val.py:22-42 and B/core/quant/int.py:160 -> scale_out; B/core/stats/stats_wrapper.py:61-66 ->
  * running).  No wave waits for another.  Results are the bits of bvq_absmax_scale[_running] (a max is exact).
  * stat_dtype: BVQ_F32 (the batch-sharded route all-reduces it) or the dtype of x.  scale_out / running: nullable.
+ * Not covered (bvq_absmax_onepass_supported: 0): a whole-tensor statistic and per-channel layouts with more than 512
+ * units per channel -- hundreds of arrivals at one word cost more than the finishing launch they would save.
  * arrive: `arrive_words` >= 2 * channels uint32 words in device memory that are ALL ZERO when the launch starts;
  *   the finishing waves hand them back as zeros, so a caller keeps ONE such buffer per stream, cleared once when
  *   it is allocated, and never clears it again (launches on one stream are ordered; do not share it between streams).

@@ -31,6 +31,10 @@ SHAPES = [  # (outer, channels, inner)
     (1, 64, 4608),      # weight-like: outer = 1
     (130, 300, 392),    # more units than persistent waves, odd counts
     (2, 2, 17),         # tiny, ragged (vector width 1)
+    (1, 1, 4096 * 100 + 17),  # whole-tensor statistic: workgroup -> shard -> top arrival, ragged end
+    (64, 1, 3136),      # whole-tensor statistic of a small activation (fewer workgroups than a full set of shards)
+    (1, 1, 5),          # whole-tensor statistic of five elements
+    (3, 2, 700000),     # two channels of ~700 units each: too many arrivals per channel -> the two-launch route serves
 ]
 
 
@@ -42,7 +46,8 @@ def test_absmax_onepass_equals_two_launches(dn, shape):
     torch.manual_seed(123456)
     x = (torch.randn(outer, ch, inner, device=DEV) * 3).to(DT[dn])
     x[0, 0, 0] = -0.0
-    x[:, 1, :] = 0.0          # an all-zero channel: the lower bound on the scale decides
+    if ch > 1:
+        x[:, 1, :] = 0.0      # an all-zero channel: the lower bound on the scale decides
     flat = x.reshape(-1)
     covered = bool(nat.lib.bvq_absmax_onepass_supported(nat.dtype_code(x.dtype), flat.data_ptr(), outer, ch, inner))
     for pre in (0, 1):
@@ -109,7 +114,8 @@ def test_backward_onepass_equals_two_launches(dn, shape):
     torch.manual_seed(654321)
     x = (torch.randn(outer, ch, inner, device=DEV) * 3).to(DT[dn])
     g = torch.randn(outer, ch, inner, device=DEV).to(DT[dn])
-    x[:, 1, :] = 0.0                       # every element attains the statistic: the first one takes the deposit
+    if ch > 1:
+        x[:, 1, :] = 0.0                   # every element attains the statistic: the first one takes the deposit
     x[outer - 1, 0, inner - 1] = 40.0      # channel 0: the arg-max is the very last element (ragged ends included)
     if outer > 1:
         x[0, 2 % ch, 0] = -50.0
