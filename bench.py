@@ -517,7 +517,11 @@ def main():
     if timer is not None:
         nat.set_kernel_timer(timer)
     job = Job(kind, dtype, device, group, rank, act_shape=shard_shape)
-    elapsed = timed_run(job, args.steps, args.warmup, settle, world, device, timer, args.timer_stride, on_gpu=on_gpu)
+    # (a step whose calls are bracketed runs through the Python Functions so that the brackets see the C-ABI calls; one
+    #  rank's shard of a strong-scaled split is host-bound there -- 0.27 against 0.16 ms, profiles/r03_strong_scaling.md --
+    #  so with N > 1 fewer steps are bracketed)
+    stride = args.timer_stride if world == 1 else max(args.timer_stride, 16)
+    elapsed = timed_run(job, args.steps, args.warmup, settle, world, device, timer, stride, on_gpu=on_gpu)
     if timer is not None:
         nat.set_kernel_timer(None)
     main_m = Measurement(job, elapsed, args.steps, world, timer)

@@ -214,6 +214,37 @@ __global__ __launch_bounds__(kBlock) void abs_affine_bwd_kernel(Tiling t, const 
   }
 }
 
+// the same for channel-last layouts (short `inner`): the tensor is rows of L = channels * inner elements; a thread owns
+// one 16-byte column chunk -- its 8 (4) channels and their coefficients never change -- and walks down the rows with a
+// grid stride in y (consecutive threads read consecutive chunks of a row: coalesced)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void abs_affine_bwd_cols_kernel(const void* x, const float* ca, const float* cb,
+                                                                     void* dx, int64_t rows, int64_t L, int64_t inner) {
+  constexpr int VEC = elem<T>::vec;
+  const int64_t cc = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // column chunk
+  if (cc * VEC >= L) return;
+  float a[VEC], b[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int64_t c = (cc * VEC + k) / inner;
+    a[k] = ca[c];
+    b[k] = cb[c];
+  }
+  const T* __restrict__ xp = reinterpret_cast<const T*>(x) + cc * VEC;
+  T* __restrict__ dp = reinterpret_cast<T*>(dx) + cc * VEC;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const vec_t<T, VEC> xv = load_vec<T, VEC>(xp + r * L);
+    vec_t<T, VEC> dv;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float xf = to_f<T>(xv.v[k]);
+      const float m = a[k] + b[k] * fabsf(xf);
+      dv.v[k] = from_f<T>(xf > 0.f ? m : (xf < 0.f ? -m : (xf == 0.f ? 0.f : xf)));  // NaN in, NaN out
+    }
+    store_vec<T, VEC>(dp + r * L, dv);
+  }
+}
+
 // ---- column-mapped abs-max (ColsPlan in bvq_common.h) -------------------------------------------------
 // a lane keeps one running maximum per column of its chunk and writes them as partial row
 // (row block * rpp + sub row) of the [partial rows][L] array the finishing kernel reduces
@@ -266,6 +297,74 @@ __global__ __launch_bounds__(kBlock) void absmax_cols_kernel(ColsStatArgs a) {
     uint32_t* out = a.part + (rblk * a.p.rpp + sub) * a.p.L + (int64_t)chunk * VEC;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) out[k] = m[k];
+  }
+}
+
+// ---- column-mapped moments (AbsAve / MeanSigmaStd on channel-last layouts) ---------------------------------------
+// the same decomposition: a lane keeps sum(|x| - p) and sum((|x| - p)^2) per column of its chunk (p: the pivot of the
+// column's channel, moments_pivot above) and writes them as its partial row of two [partial rows][L] float arrays;
+// the fold of the scale-gradient sums (double accumulation, rows in order) and channel_sum_kernel finish them.
+struct ColsMomentArgs {
+  ColsPlan p;
+  const void* x;
+  float* part1;  // [prows][L] sum of d
+  float* part2;  // [prows][L] sum of d * d
+  float* pivot;  // [channels], written by row block 0
+  int64_t inner;
+};
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(kBlock) void absmoments_cols_kernel(ColsMomentArgs a) {
+  constexpr int VEC = elem<T>::vec;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (unit >= a.p.units) return;
+  const int64_t rblk = unit / a.p.strips;
+  const int32_t strip = (int32_t)(unit - rblk * a.p.strips);
+  const int32_t sub = lane / a.p.lpr;
+  const int32_t chunk = strip * kWave + (lane - sub * a.p.lpr);
+  const bool active = sub < a.p.rpp && chunk < a.p.cps;
+  if (!active) return;
+  const int64_t row0 = rblk * a.p.rb + sub;
+  const int64_t row_end = (rblk + 1) * a.p.rb < a.p.rows ? (rblk + 1) * a.p.rb : a.p.rows;
+  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + (int64_t)chunk * VEC;
+  float pv[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int64_t col = (int64_t)chunk * VEC + k;
+    const int64_t c = col / a.inner;
+    pv[k] = moments_pivot<T>(a.x, c * a.inner);  // |x| of the channel's first element (row 0)
+    s1[k] = s2[k] = 0.f;
+    if (rblk == 0 && sub == 0 && col == c * a.inner) a.pivot[c] = pv[k];
+  }
+  constexpr int kU = 4;
+  for (int64_t r = row0; r < row_end; r += (int64_t)kU * a.p.rpp) {
+    vec_t<T, VEC> xv[kU];
+    bool ok[kU];
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      const int64_t rr = r + (int64_t)j * a.p.rpp;
+      ok[j] = rr < row_end;
+      xv[j] = load_vec<T, VEC, NT>(xp + (ok[j] ? rr : row0) * a.p.L);
+    }
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      if (ok[j]) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const float d = fabsf(to_f<T>(xv[j].v[k])) - pv[k];
+          s1[k] += d;
+          s2[k] += d * d;
+        }
+      }
+    }
+  }
+  const int64_t base = (rblk * a.p.rpp + sub) * a.p.L + (int64_t)chunk * VEC;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    a.part1[base + k] = s1[k];
+    a.part2[base + k] = s2[k];
   }
 }
 
@@ -1346,7 +1445,14 @@ extern "C" int bvq_absmax_scale_running(int pre_op, int dtype, const void* x, in
 extern "C" int64_t bvq_abs_moments_workspace_bytes(int dtype, int64_t outer, int64_t channels, int64_t inner) {
   if (bad_dtype(dtype) || outer < 0 || channels < 1 || inner < 0) return -1;
   const int64_t units = worst_units(dtype, outer, channels, inner);
-  return 2 * units * (int64_t)sizeof(float) + 8 + channel_sums_mid_bytes(units / channels + 1, channels) + 256;
+  int64_t need = 2 * units * (int64_t)sizeof(float) + 8 + channel_sums_mid_bytes(units / channels + 1, channels) + 256;
+  const ColsPlan cp = cols_plan(dtype, outer, channels, inner);
+  if (cp.ok) {  // column-mapped: two [partial rows + fold scratch][L] float arrays
+    const int64_t cols = 2 * (cp.prows + cols_fold_scratch_rows(cp.prows)) * cp.L * (int64_t)sizeof(float) + 8 +
+                         channel_sums_mid_bytes(inner, channels) + 256;
+    if (cols > need) need = cols;
+  }
+  return need;
 }
 
 extern "C" int bvq_abs_moments(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
@@ -1369,6 +1475,49 @@ extern "C" int bvq_abs_moments(int dtype, const void* x, int64_t outer, int64_t 
     set_error("bvq_abs_moments: null pointer");
     return BVQ_ERR_INVALID;
   }
+  const bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
+  // channel axis last (or nearly): column-mapped units
+  const ColsPlan cp =
+      (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? cols_plan(dtype, outer, channels, inner) : ColsPlan{};
+  if (cp.ok) {
+    const int64_t rows_all = cp.prows + cols_fold_scratch_rows(cp.prows);
+    const int64_t mid_off_c = ((2 * rows_all * cp.L * (int64_t)sizeof(float) + 7) / 8) * 8;
+    if (workspace_bytes < mid_off_c + channel_sums_mid_bytes(inner, channels)) {
+      set_error("bvq_abs_moments: workspace too small");
+      return BVQ_ERR_WORKSPACE;
+    }
+    ColsMomentArgs ca;
+    ca.p = cp;
+    ca.x = x;
+    ca.part1 = reinterpret_cast<float*>(workspace);
+    ca.part2 = ca.part1 + rows_all * cp.L;
+    ca.pivot = sums + 2 * channels;
+    ca.inner = inner;
+    const dim3 cgrid(grid_for_units(cp.units)), cblock(kBlock);
+#define BVQ_MOMC(T)                                                   \
+  do {                                                                \
+    if (nt)                                                           \
+      absmoments_cols_kernel<T, true><<<cgrid, cblock, 0, st>>>(ca);  \
+    else                                                              \
+      absmoments_cols_kernel<T, false><<<cgrid, cblock, 0, st>>>(ca); \
+  } while (0)
+    if (dtype == BVQ_F32)
+      BVQ_MOMC(float);
+    else if (dtype == BVQ_BF16)
+      BVQ_MOMC(bf16_t);
+    else
+      BVQ_MOMC(f16_t);
+#undef BVQ_MOMC
+    int rc0 = check_launch("bvq_abs_moments/cols");
+    if (rc0) return rc0;
+    float *f1 = nullptr, *f2 = nullptr;
+    launch_cols_fold_sum_min(ca.part1, nullptr, cp.prows, cp.L, ca.part1 + cp.prows * cp.L, nullptr, &f1, nullptr, st);
+    launch_cols_fold_sum_min(ca.part2, nullptr, cp.prows, cp.L, ca.part2 + cp.prows * cp.L, nullptr, &f2, nullptr, st);
+    // the folded rows are the (nob = 1, channels, ppr = inner) layout of the finishing sums
+    launch_channel_sums(f1, f2, sums, sums + channels, 1, (int32_t)channels, inner,
+                        reinterpret_cast<char*>(workspace) + mid_off_c, st);
+    return check_launch("bvq_abs_moments/cols_sums");
+  }
   int vec;
   StatArgs a;
   a.t = stat_tiling(dtype, x, nullptr, outer, channels, inner, vec);
@@ -1382,7 +1531,6 @@ extern "C" int bvq_abs_moments(int dtype, const void* x, int64_t outer, int64_t 
   a.part_a = reinterpret_cast<uint32_t*>(workspace);
   a.part_b = a.part_a + a.t.units;
   a.pivot = sums + 2 * channels;
-  const bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
   const dim3 grid(grid_for_units(a.t.units)), block(kBlock);
 #define BVQ_MOM(T)                                                     \
   do {                                                                 \
@@ -1421,6 +1569,22 @@ extern "C" int bvq_abs_affine_bwd(int dtype, const void* x, const float* a, cons
     return BVQ_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0 &&
+      cols_plan(dtype, outer, channels, inner).ok) {  // channel axis last (or nearly): flat chunks, channel per element
+    const int64_t L = channels * inner, cps = L / (16 / dtype_size(dtype));
+    const int64_t gx = (cps + kBlock - 1) / kBlock;
+    int64_t gy = (16384 + gx - 1) / gx;  // ~16 k workgroups in all
+    gy = gy > outer ? outer : gy;
+    gy = gy > 65535 ? 65535 : (gy < 1 ? 1 : gy);
+    const dim3 fgrid((unsigned)gx, (unsigned)gy), fblock(kBlock);
+    if (dtype == BVQ_F32)
+      abs_affine_bwd_cols_kernel<float><<<fgrid, fblock, 0, st>>>(x, a, b, dx, outer, L, inner);
+    else if (dtype == BVQ_BF16)
+      abs_affine_bwd_cols_kernel<bf16_t><<<fgrid, fblock, 0, st>>>(x, a, b, dx, outer, L, inner);
+    else
+      abs_affine_bwd_cols_kernel<f16_t><<<fgrid, fblock, 0, st>>>(x, a, b, dx, outer, L, inner);
+    return check_launch("bvq_abs_affine_bwd/cols");
+  }
   int vec;
   const Tiling t = stat_tiling(dtype, x, dx, outer, channels, inner, vec);
   const dim3 grid(grid_for_units(t.units)), block(kBlock);

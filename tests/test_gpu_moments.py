@@ -114,3 +114,35 @@ def test_full_size_moments_and_learned_sigma():
     m2 = MeanLearnedSigmaStd(1.0, (), None)
     m2.load_state_dict({'learned_sigma': torch.tensor(4.0)})
     assert float(m2.sigma) == 4.0 and list(m2.state_dict().keys()) == ['sigma']
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16], ids=['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(300, 512, 1), (257, 64, 1), (65, 1000, 1), (33, 16, 49), (5000, 8, 2)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_column_mapped_moments_equal_row_mapped(dtype, shape):
+    """channel-last layouts (short `inner`): bvq_abs_moments and bvq_abs_affine_bwd on the column-mapped units against
+    the row-mapped route (a misaligned copy of the same tensor takes it): sums within float32 accumulation error of
+    the summed magnitudes, pivots and dx bit for bit"""
+    from brevitas_amd import _native as nat
+    outer, ch, inner = shape
+    torch.manual_seed(123456)
+    x = (torch.randn(outer, ch, inner, device=DEV) * 3 + 1).to(dtype).reshape(-1)
+    buf = torch.empty(x.numel() + 8, dtype=dtype, device=DEV)
+    xm = buf[1:1 + x.numel()]          # 2 or 4 bytes past a 16-byte boundary: the row-mapped route
+    xm.copy_(x)
+    sc = nat.abs_moments(x, outer, ch, inner).double()
+    sr = nat.abs_moments(xm, outer, ch, inner).double()
+    assert torch.equal(sc[2 * ch:], sr[2 * ch:])                    # the channels' pivots
+    p = sc[2 * ch:].reshape(1, ch, 1)
+    d = (x.double().reshape(outer, ch, inner).abs() - p)
+    mag1, mag2 = d.abs().sum(dim=(0, 2)), (d * d).sum(dim=(0, 2))
+    eps = 2.0 ** -22
+    assert torch.all((sc[:ch] - sr[:ch]).abs() <= eps * 8 * mag1 + 1e-30)
+    assert torch.all((sc[ch:2 * ch] - sr[ch:2 * ch]).abs() <= eps * 8 * mag2 + 1e-30)
+    assert torch.all((sc[:ch] - d.sum(dim=(0, 2))).abs() <= eps * 8 * mag1 + 1e-30)   # and against float64
+    a = torch.randn(ch, device=DEV)
+    b = torch.randn(ch, device=DEV)
+    dc = nat.abs_affine_bwd(x, a, b, outer, ch, inner)
+    dr = nat.abs_affine_bwd(xm, a, b, outer, ch, inner)
+    assert torch.equal(dc.view(torch.int16 if dc.element_size() == 2 else torch.int32),
+                       dr.view(torch.int16 if dr.element_size() == 2 else torch.int32))

@@ -11,7 +11,9 @@ RUNS = [('act_per_channel_bf16', []), ('act_per_tensor_bf16', []), ('act_per_cha
         # config 4 on ONE GPU of the eight it names: that GPU's 128 rows of the batch of 1024 (as in rounds 1 and 2)
         ('qconv_layer3', ['--steps', '1000', '--warmup', '100', '--act-shape', '128,1024,14,14']),
         ('qlinear_8192', ['--steps', '500', '--warmup', '50']), ('act_per_channel_bf16', ['--shard-path']),
-        ('act_per_channel_bf16', ['--steps', '20', '--warmup', '5'])]
+        ('act_per_channel_bf16', ['--steps', '20', '--warmup', '5']),
+        # the same call WITHOUT the 35 untimed clock-settling steps bench.py runs before the warm-up by default
+        ('act_per_channel_bf16', ['--steps', '20', '--warmup', '5', '--no-settle'])]
 
 
 def main():

@@ -1,6 +1,6 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/s5_pmc
+OUT=$ROOT/gpurun_out/${1:-pmc_sq}
 rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 pass() {
