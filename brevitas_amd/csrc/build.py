@@ -18,15 +18,17 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, 'libbvq.so')
 OBJ_DIR = os.path.join(ROOT, 'build', 'bvq')
 
-# (source, extra -D flags, object name): the quantizer file is split into its forward half, the backward entry points and
-# the row-mapped backward kernel per dtype family (BVQ_PART, see the top of bvq_fakequant.hip)
+# (source, extra -D flags, object name).  The quantizer is split by kernel family: forward; backward entry points with the
+# column-mapped / finishing kernels; the row-mapped backward kernel per dtype family (the long poles of the build).
 SOURCES = [('bvq_common.hip', [], 'bvq_common.o'), ('bvq_elementwise.hip', [], 'bvq_elementwise.o'),
-           ('bvq_stats.hip', [], 'bvq_stats.o'), ('bvq_select.hip', [], 'bvq_select.o'), ('bvq_variants.hip', [], 'bvq_variants.o'), ('bvq_fakequant.hip', ['BVQ_PART=1'], 'bvq_fakequant_fwd.o'),
-           ('bvq_fakequant.hip', ['BVQ_PART=2'], 'bvq_fakequant_bwd.o'),
-           ('bvq_fakequant.hip', ['BVQ_PART=21'], 'bvq_fakequant_bwd_bf16.o'),
-           ('bvq_fakequant.hip', ['BVQ_PART=22'], 'bvq_fakequant_bwd_f16.o'),
-           ('bvq_fakequant.hip', ['BVQ_PART=23'], 'bvq_fakequant_bwd_f32.o')]
-HEADERS = ['bvq_common.h', 'bvq_quant_math.h', 'bvq_ties.h', 'bvq_sums.h', os.path.join(ROOT, 'include', 'bvq.h')]
+           ('bvq_stats.hip', [], 'bvq_stats.o'), ('bvq_select.hip', [], 'bvq_select.o'),
+           ('bvq_variants.hip', [], 'bvq_variants.o'), ('bvq_fakequant_fwd.hip', [], 'bvq_fakequant_fwd.o'),
+           ('bvq_fakequant_bwd.hip', [], 'bvq_fakequant_bwd.o'),
+           ('bvq_fakequant_bwd_bf16.hip', [], 'bvq_fakequant_bwd_bf16.o'),
+           ('bvq_fakequant_bwd_f16.hip', [], 'bvq_fakequant_bwd_f16.o'),
+           ('bvq_fakequant_bwd_f32.hip', [], 'bvq_fakequant_bwd_f32.o')]
+HEADERS = ['bvq_common.h', 'bvq_quant_math.h', 'bvq_ties.h', 'bvq_sums.h', 'bvq_fakequant.h', 'bvq_fakequant_bwd.h',
+           os.path.join(ROOT, 'include', 'bvq.h')]
 
 # -ffp-contract=off: the reference rounds after every op; a contracted mul+add would not.
 # hipcc's default fp32 division is correctly rounded (no -ffast-math, no approximate reciprocal).

@@ -1101,9 +1101,6 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
   }
   hipStream_t st = (hipStream_t)stream;
   bool nt = n * (int64_t)dtype_size(dtype) >= nt_threshold_bytes();
-#ifdef BVQ_CACHE_EXPERIMENT
-  if (getenv("BVQ_X_STAT_NT")) nt = atoi(getenv("BVQ_X_STAT_NT")) != 0;
-#endif
   // channel axis last (or nearly): column-mapped units, same finishing kernel
   const ColsPlan cp =
       (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? cols_plan(dtype, outer, channels, inner) : ColsPlan{};
@@ -1158,9 +1155,6 @@ static int stats_impl(int kind, int pre_op, int dtype, const void* x, int64_t ou
   int vec;
   StatArgs a;
   a.t = stat_tiling(dtype, x, nullptr, outer, channels, inner, vec, true);
-#ifdef BVQ_CACHE_EXPERIMENT
-  if (getenv("BVQ_X_STAT_REV")) a.t.reverse = atoi(getenv("BVQ_X_STAT_REV"));
-#endif
   // A whole-tensor abs-max as long units: at most kFinishSlice pieces, each walked by one wave of the software-pipelined
   // kernel of the one-launch route -- the partials then fit ONE finishing launch (the short-unit tiling leaves ~10^4-10^5
   // partials and needs two): [8192,8192] bf16 34 -> 26 us, profiles/r03_onepass.txt section 5.

@@ -1,5 +1,5 @@
 // bvq_ties.h -- bookkeeping of the elements that attain a max/min statistic ("ties"), shared by the
-// statistics backward (bvq_stats.hip) and the fused quantizer backward (bvq_fakequant.hip).
+// statistics backward (bvq_stats.hip) and the fused quantizer backward (bvq_fakequant_bwd.h).
 //
 // tie_info layout (unsigned 64-bit words, device memory, bvq_tie_info_bytes(channels) bytes):
 //   channels > 1 : first[c]  = smallest (outer*inner + i) position matching stat[c]   (init: ~0)

@@ -573,7 +573,7 @@ int bvq_variant_bwd(const bvq_variant_desc* desc, const void* g, const void* x, 
 
 /* Diagnostic entry (no reference counterpart): the float32 quotient the float16 quantizer kernels compute for a
  * numerator a[i] and a scale scales[j] -- the product with the correctly rounded reciprocal, corrected by one exact
- * remainder step (brevitas_amd/csrc/bvq_fakequant.hip, DivF16R) -- out[j * n_a + i], float32 device buffers.  The
+ * remainder step (brevitas_amd/csrc/bvq_fakequant.h, DivF16R) -- out[j * n_a + i], float32 device buffers.  The
  * tests compare every float16 numerator x every float16 scale in [2^-14, 2^14] with a / s (tests/test_gpu_fastdiv.py). */
 int bvq_selftest_div_f16r(const float* a, int32_t n_a, const float* scales, int32_t n_s, float* out,
                           bvq_stream_t stream);

@@ -1,5 +1,5 @@
 """Exhaustive check of the claim behind the bf16 fast path of the quantizer kernels
-(brevitas_amd/csrc/bvq_fakequant.hip, DivBf16): for every bf16 scale s in [2^-14, 2^14] and EVERY
+(brevitas_amd/csrc/bvq_fakequant.h, DivBf16): for every bf16 scale s in [2^-14, 2^14] and EVERY
 bf16 numerator a (all 65536 bit patterns),
 
     RN_bf16( RN_f32(a) * RN_f32(1 / s) )  ==  RN_bf16( RN_f32(a / s) )
@@ -72,7 +72,7 @@ def test_reciprocal_multiply_is_exact_for_f16_over_f16_outside_the_subnormal_gua
 
 
 def refined_quotient(a, s):
-    """DivF16R of brevitas_amd/csrc/bvq_fakequant.hip emulated exactly: q0 = RN32(a * r) with r = RN32(1 / s),
+    """DivF16R of brevitas_amd/csrc/bvq_fakequant.h emulated exactly: q0 = RN32(a * r) with r = RN32(1 / s),
     rem = fma(-q0, s, a), q = fma(rem, r, q0), then what v_div_fixup_f32 does for zero / infinite / NaN numerators
     and for the sign.  The two fmas are evaluated in float64, where the first is exact (35-bit product, operands a
     few binades apart) and the second is exact up to ONE rounding to 53 bits: the rare results that land exactly on

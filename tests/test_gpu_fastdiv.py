@@ -1,4 +1,4 @@
-"""float16 fast paths (DivF16 and DivF16R, brevitas_amd/csrc/bvq_fakequant.hip): the arithmetic claims on every
+"""float16 fast paths (DivF16 and DivF16R, brevitas_amd/csrc/bvq_fakequant.h): the arithmetic claims on every
 float16 numerator x every float16 scale in [2^-14, 2^14], and the kernels on inputs full of tiny and subnormal
 values (the quotients that must take the IEEE division) against the CPU oracle."""
 import numpy as np

@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """ISA of a kernel's hot loop, with the instructions counted per class and per 16-byte chunk.
 
-    python tools/hot_loop_isa.py [--part 2] [--symbol MANGLED] [--chunks-per-trip N] [--asm FILE]
+    python tools/hot_loop_isa.py [--part bwd_bf16] [--symbol MANGLED] [--chunks-per-trip N] [--asm FILE]
 
-Compiles brevitas_amd/csrc/bvq_fakequant.hip to gfx950 assembly (hipcc -S --cuda-device-only, the
-library's own flags; minutes for the backward half), takes one kernel's body, finds its innermost
+Compiles brevitas_amd/csrc/bvq_fakequant_<part>.hip to gfx950 assembly (hipcc -S --cuda-device-only, the
+library's own flags; about a minute for a backward family), takes one kernel's body, finds its innermost
 loops (a conditional branch back to an earlier label) and prints the one holding the most global
 loads / stores: the listing, the instruction mix and the count per 16-byte chunk a lane moves.
 The default symbol is the headline step's backward (bf16 tensor and arithmetic, 8 elements per lane,
@@ -19,7 +19,7 @@ import sys
 sys.path.insert(0, '.')
 from brevitas_amd.csrc.build import CSRC, FLAGS, ROOT, _hipcc  # noqa: E402
 
-HEADLINE_BWD = '_ZN3bvq20fakequant_bwd_kernelIDF16bDF16bLi8ELi0ELi3ELb1ELb1EEEvNS_9QuantArgsE'
+HEADLINE_BWD = '_ZN3bvq20fakequant_bwd_kernelIDF16bDF16bLi8ELi0ELi5ELb1ELb1EEEvNS_9QuantArgsE'  # one-launch form (mode 5)
 
 
 def classify(op):
@@ -95,14 +95,14 @@ def main():
             if a == name:
                 return args[i + 1]
         return default
-    part, symbol = opt('--part', '2'), opt('--symbol', HEADLINE_BWD)
+    part, symbol = opt('--part', 'bwd_bf16'), opt('--symbol', HEADLINE_BWD)
     per_trip = int(opt('--chunks-per-trip', '0'))
     asm_path = opt('--asm', None)
     if asm_path is None:
-        asm_path = '/tmp/bvq_part%s.s' % part
+        asm_path = '/tmp/bvq_fakequant_%s.s' % part
         cmd = [_hipcc()] + [f for f in FLAGS if not f.startswith('-W')] + \
-            ['-DBVQ_PART=' + part, '-S', '--cuda-device-only', '-I', os.path.join(ROOT, 'include'),
-             os.path.join(CSRC, 'bvq_fakequant.hip'), '-o', asm_path]
+            ['-S', '--cuda-device-only', '-I', os.path.join(ROOT, 'include'),
+             os.path.join(CSRC, 'bvq_fakequant_%s.hip' % part), '-o', asm_path]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             sys.exit(r.stderr)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Register / occupancy table of the kernels of one translation unit (hipcc -Rpass-analysis=kernel-resource-usage).
 
-    python tools/kernel_resources.py brevitas_amd/csrc/bvq_fakequant.hip [-DBVQ_PART=2 ...] [--filter NAME]
+    python tools/kernel_resources.py brevitas_amd/csrc/bvq_fakequant_bwd_bf16.hip [-DFLAG ...] [--filter=NAME]
 """
 import re
 import subprocess
