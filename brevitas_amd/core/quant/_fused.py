@@ -290,10 +290,20 @@ class VariantFn(Function):
         return (dx if ctx.needs_input_grad[0] else None), ds, dp, None, None, None, None
 
 
+def _dimensioned_wider_scalar(x: Tensor, t: Optional[Tensor]) -> bool:
+    """a ONE-element operand that still has dimensions (shape (1,), (1,1,1,1)) and a dtype wider than x's: torch's type
+    promotion treats it as a tensor, not as a scalar -- every op with it computes and returns in ITS dtype -- while the
+    variant kernels' one-element operands follow the 0-dim rule (rounded to x's dtype, bvq_scalar_mode).  Such operands
+    take the op-by-op route."""
+    return t is not None and t.numel() == 1 and t.dim() > 0 and torch.promote_types(x.dtype, t.dtype) != x.dtype
+
+
 def variant_plan(x: Tensor, scale: Tensor, *others: Optional[Tensor]) -> Optional[Plan]:
     """layout plan for a variant kernel: x against `scale`; every other scale-like operand must share scale's shape
     and dtype, every zero-point must be a single element that needs no gradient"""
     if not config.FUSED_PATHS or torch._C._get_tracing_state() is not None:
+        return None
+    if _dimensioned_wider_scalar(x, scale):
         return None
     p = plan(x, scale, _zero_zero_point(x.device) if x.is_cuda else scale)
     if p is None or p.nhwc or not x.is_contiguous():
@@ -304,8 +314,10 @@ def variant_plan(x: Tensor, scale: Tensor, *others: Optional[Tensor]) -> Optiona
     return p
 
 
-def scalar_zero_point_ok(*zps: Optional[Tensor]) -> bool:
-    return all(z is None or (z.numel() == 1 and z.is_cuda and z.dtype in _FLOATS and not z.requires_grad) for z in zps)
+def scalar_zero_point_ok(*zps: Optional[Tensor], x: Optional[Tensor] = None) -> bool:
+    """x given: also refuse a dimensioned one-element zero-point that would promote x (see _dimensioned_wider_scalar)"""
+    return all(z is None or (z.numel() == 1 and z.is_cuda and z.dtype in _FLOATS and not z.requires_grad
+                             and not (x is not None and _dimensioned_wider_scalar(x, z))) for z in zps)
 
 
 class StatsPlan(NamedTuple):

@@ -375,7 +375,7 @@ class TruncIntQuant(torch.nn.Module):
         out_bw = getattr(output_bit_width, 'bvq_host_value', None)
         round_mode = getattr(self.float_to_int_impl, 'bvq_round_mode', None)
         if in_bw is not None and out_bw is not None and round_mode is not None and \
-                _fused.scalar_zero_point_ok(zero_point):
+                _fused.scalar_zero_point_ok(zero_point, x=x):
             p = _fused.variant_plan(x, scale)
             ct = torch.result_type(x, scale)
             if p is not None and (ct == x.dtype or ct == torch.float32):

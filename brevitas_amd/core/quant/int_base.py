@@ -235,7 +235,7 @@ class DecoupledIntQuant(torch.nn.Module):
         bw = getattr(bit_width, 'bvq_host_value', None)
         if round_mode is None or clamp_ste is None or bw is None or bit_width.requires_grad:
             return None
-        if not _fused.scalar_zero_point_ok(zero_point, pre_zero_point):
+        if not _fused.scalar_zero_point_ok(zero_point, pre_zero_point, x=x):
             return None
         p = _fused.variant_plan(x, scale, pre_scale)
         if p is None:

@@ -510,7 +510,9 @@ class KLMinimizerThreshold(torch.nn.Module):
 
     def _histogram(self, x: Tensor, absmax: Tensor) -> Tensor:
         if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and self.num_bins <= 8192:
-            return nat.histc(x.detach().reshape(-1), absmax.detach(), self.num_bins).cpu()
+            flat = x.detach().reshape(-1)
+            if flat.data_ptr() % 16 == 0:  # (bvq_histc takes 16-byte aligned data; a view into a buffer's middle below)
+                return nat.histc(flat, absmax.detach(), self.num_bins).cpu()
         a = float(absmax)
         return torch.histc(x.detach().float().cpu(), bins=self.num_bins, min=-a, max=a).int()
 

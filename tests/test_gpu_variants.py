@@ -140,6 +140,40 @@ def test_variant_kernels_are_the_route_taken(monkeypatch):
     assert calls == [nat.VAR_BINARY, nat.VAR_TERNARY]
 
 
+def test_dimensioned_one_element_operand_wider_than_x_takes_the_op_by_op_route(monkeypatch):
+    """torch's type promotion: a one-element scale with dimensions -- shape (1,) -- and a wider dtype than x promotes
+    every op to ITS dtype (the ternary threshold compare and the binary clamp then run in float32), a 0-dim one does
+    not.  The fused kernels follow the 0-dim rule, so the dimensioned operand must take the op-by-op route and equal
+    the reference composition bit for bit; same for a dimensioned float32 zero-point of the truncating quantizer."""
+    from brevitas_amd import _native as nat
+    from brevitas_amd.core.bit_width import BitWidthConst
+    from brevitas_amd.core.function_wrapper import RoundSte
+    from brevitas_amd.core.quant import ClampedBinaryQuant, TernaryQuant, TruncIntQuant
+    from brevitas_amd.core.scaling import ParameterScaling
+    calls = []
+    real = nat.variant_fwd
+    monkeypatch.setattr(nat, 'variant_fwd', lambda *a, **k: (calls.append(a[0].kind), real(*a, **k))[1])
+    torch.manual_seed(3)
+    x = (torch.randn(64, 33, device=DEV) * 0.5).to(torch.bfloat16)
+    s1 = torch.tensor([0.40234375 + 2.0 ** -12], device=DEV)            # float32, shape (1,): not a bf16 value
+    for make in (lambda: TernaryQuant(ParameterScaling(s1.detach().cpu().clone(), scaling_shape=(1,)), 0.5),
+                 lambda: ClampedBinaryQuant(ParameterScaling(s1.detach().cpu().clone(), scaling_shape=(1,)))):
+        y = make().to(DEV)(x)[0]
+        y_cpu = make()(x.cpu())[0]            # the reference's op composition on CPU tensors (brevitas_amd/_aten.py)
+        assert y.dtype == torch.float32       # promoted by the dimensioned float32 scale
+        assert torch.equal(y.cpu(), y_cpu)
+    tq = TruncIntQuant(RoundSte(), BitWidthConst(4)).to(DEV)
+    zp1 = torch.tensor([1.0], device=DEV)                                # float32, shape (1,)
+    sc = torch.tensor(0.125, device=DEV, dtype=torch.bfloat16)
+    y = tq(x, sc, zp1, torch.tensor(8.0, device=DEV))[0]
+    y_cpu = TruncIntQuant(RoundSte(), BitWidthConst(4))(x.cpu(), sc.cpu(), zp1.cpu(), torch.tensor(8.0))[0]
+    assert y.dtype == torch.float32 and torch.equal(y.cpu(), y_cpu)
+    assert calls == [], 'a dimensioned wider one-element operand reached a fused variant kernel'
+    # the 0-dim forms of the same operands do take the kernels
+    TernaryQuant(ParameterScaling(float(s1)), 0.5).to(DEV)(x)
+    assert calls == [nat.VAR_TERNARY]
+
+
 def test_doctests():
     from brevitas_amd.core.quant import DecoupledIntQuant, TernaryQuant
     from brevitas_amd.core.scaling import ConstScaling

@@ -41,6 +41,13 @@ def test_kl_threshold_on_the_device(c):
     m = KLMinimizerThreshold(c['signed'], BitWidthConst(c['bits'])).to(dev)
     out = m(x)
     assert out.is_cuda and abs(float(out) - float(c.f32('out'))) <= 1e-6 * abs(float(c.f32('out')))
+    # a view into the middle of a buffer (not 16-byte aligned): the module must serve it like the reference does
+    buf = torch.empty(x.numel() + 4, device=dev)
+    xv = buf[1:1 + x.numel()]
+    xv.copy_(x.reshape(-1))
+    assert xv.data_ptr() % 16 != 0
+    out_v = m(xv.reshape(x.shape))
+    assert abs(float(out_v) - float(out)) <= 1e-6 * abs(float(out))
     for dt in (torch.bfloat16, torch.float16):                 # 16-bit inputs: same kernel family
         xh = x.to(dt)
         ah = xh.abs().max()
