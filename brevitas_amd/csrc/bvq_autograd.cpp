@@ -266,7 +266,8 @@ class ActStatsFakeQuant : public torch::autograd::Function<ActStatsFakeQuant> {
     }
     if (sharded) {
       // the statistic of the whole batch is the max over the shards (exact, order-independent)
-      if (p.group->getSize() > 1) {
+      // (issued with one rank too: a one-rank group then exercises the same c10d / RCCL calls as N ranks)
+      {
         std::vector<at::Tensor> ts{stat32};
         c10d::AllreduceOptions opts;
         opts.reduceOp = c10d::ReduceOp::MAX;
@@ -332,11 +333,8 @@ class ActStatsFakeQuant : public torch::autograd::Function<ActStatsFakeQuant> {
                                         dx.data_ptr(), msg.data_ptr<double>(), pos.data_ptr<int64_t>(), rank, ws.data_ptr(),
                                         wsb, arr, arr_n, st),
               "bvq_fakequant_bwd_shard");
-        at::Tensor gathered = msg;
-        if (world > 1) {
-          gathered = at::empty({world * msg.numel()}, msg.options());
-          group->_allgather_base(gathered, msg)->wait();
-        }
+        at::Tensor gathered = at::empty({world * msg.numel()}, msg.options());
+        group->_allgather_base(gathered, msg)->wait();
         check(p_bvq_shard_unpack_deposit(d.x_dtype, x.data_ptr(), dx.data_ptr(), gathered.data_ptr<double>(), world,
                                          d.channels, rank, pos.data_ptr<int64_t>(), d.inner, sdt, qr[2], sdt, d.pre_op,
                                          nullptr, st),
