@@ -464,6 +464,71 @@ class StatsFakeQuantFn(Function):
         return dx, None, None, None, None, None, None, None, None, None
 
 
+class StatsGraphFakeQuantFn(Function):
+    """AbsMax statistic -> ANY scale-shaped map (`post`: a _StatsScaling with affine rescaling, a power-of-two
+    restriction, ...) -> / int_threshold -> IntQuant, zero zero-point (B/core/scaling/runtime.py:19-72,
+    B/core/quant/int.py:155-163).
+
+    The tensor-sized work stays on the fused kernels -- statistic (1 read), quantizer (1 read + 1 write), backward
+    (2 reads + 1 write, with the scale-gradient sums and the arg-max positions on the same reads) -- and only the map
+    itself runs as torch ops on `channels`-sized tensors, recorded here and differentiated by autograd on those small
+    tensors: dscale -> (d statistic, d affine_weight, d affine_bias); the statistic's gradient is then deposited on the
+    arg-max elements in place.  The op-by-op route it replaces sends the statistic's gradient through AbsMax's own
+    backward (a second pass over x writing a dense gradient) and adds the two x-sized gradients: 11 tensor passes
+    instead of 6.  `params`: post's parameters, passed so that autograd sees them as inputs."""
+
+    @staticmethod
+    def forward(ctx, x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, pre_op, post, *params):
+        ctx.set_materialize_grads(False)
+        xc, back = _memory_order(x, sp.channels, sp.nhwc)
+        flat = xc.reshape(-1)
+        stat = nat.stats(nat.STAT_ABSMAX, flat, sp.outer, sp.channels, sp.inner, pre_op=pre_op).view(sp.scaling_shape)
+        with torch.enable_grad():
+            s_leaf = stat.detach().requires_grad_(True)
+            scale_g = post(s_leaf) / int_threshold
+        scale = scale_g.detach()
+        zp = _zero_zero_point(x.device)
+        p = plan(xc if back is None else x, scale, zp)
+        if p is None or p.zp_pc or p.nhwc != sp.nhwc:
+            raise nat.BvqError('StatsGraphFakeQuantFn: operand layout not covered by the quantizer kernels')
+        sc = scale.reshape(-1).contiguous()
+        desc = make_desc(p, xc, sc, zp.reshape(-1), qmin, qmax, round_mode, clamp_ste, nat.OUT_DEQUANT, pre_op)
+        y = nat.fakequant_fwd(desc, xc, sc, zp.reshape(-1))
+        ctx.desc, ctx.sp, ctx.back, ctx.pre_op = desc, sp, back, pre_op
+        ctx.graph = (s_leaf, scale_g, params)
+        ctx.save_for_backward(xc, scale, zp, stat)
+        ctx.mark_non_differentiable(stat)
+        if back is not None:
+            y = y.permute(back)
+        return y, scale, stat
+
+    @staticmethod
+    def backward(ctx, gy, gscale, _gstat):
+        xc, scale, zp, stat = ctx.saved_tensors
+        desc, sp = ctx.desc, ctx.sp
+        s_leaf, scale_g, params = ctx.graph
+        none = (None,) * 9
+        ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
+        if gy is None and gscale is None:
+            return none + (None,) * len(params)
+        if gy is None:
+            gy = torch.zeros(xc.shape, dtype=ct, device=xc.device)
+        else:
+            gy = _like_memory_order(gy.to(ct), ctx.back)
+        stat_x = stat.reshape(-1).to(xc.dtype).contiguous()
+        dx, ds, _, ties = nat.fakequant_bwd(desc, gy, xc, scale.reshape(-1).contiguous(), zp.reshape(-1), True, False,
+                                            tie_stat=stat_x)
+        dscale = _reduce_like(ds, scale)
+        if gscale is not None:
+            dscale = dscale + gscale
+        grads = torch.autograd.grad(scale_g, (s_leaf,) + tuple(params), dscale, retain_graph=True, allow_unused=True)
+        dstat = grads[0]
+        if dstat is not None:
+            nat.stat_tie_apply(nat.MATCH_ABS, xc.reshape(-1), stat_x, dstat.reshape(-1).to(xc.dtype).contiguous(), ties,
+                               dx.reshape(-1), sp.outer, sp.channels, sp.inner, mode_add=True, pre_op=ctx.pre_op)
+        return (_restore(dx, ctx.back),) + none[1:] + tuple(grads[1:])
+
+
 def stats_backward(xc, scale, zp, stat, int_threshold, desc, sp, group, pre_op, back, gy, gscale):
     """backward of StatsFakeQuantFn (also the fallback of the C++ node, brevitas_amd/csrc/bvq_autograd.cpp) -> dx or None;
     sp: anything with outer / channels / inner / int_threshold"""

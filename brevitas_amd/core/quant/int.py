@@ -96,8 +96,12 @@ class RescalingIntQuant(torch.nn.Module):
         else:
             return None
         min_val = sc.stats_scaling_impl.bvq_plain_min_val()
-        if min_val is None or type(stats.stats_impl) is not AbsMax:
+        if type(stats.stats_impl) is not AbsMax:
             return None
+        # a statistic -> threshold map that is NOT the plain lower bound (affine rescaling, a power-of-two restriction):
+        # the statistic and quantizer kernels still apply, the map runs as a few scale-shaped torch ops between them and
+        # is differentiated by autograd on those small tensors (_fused.StatsGraphFakeQuantFn)
+        post = sc.stats_scaling_impl if min_val is None else None
         shape = tuple(stats.stats_output_shape)
         if type(view) is OverTensorView and stats.stats_impl.stats_reduce_dim is None:
             if shape != ():
@@ -108,7 +112,7 @@ class RescalingIntQuant(torch.nn.Module):
         else:
             return None
         qmin, qmax = int_range_host(iq.signed, iq.narrow_range, bw)
-        return dict(runtime=runtime, weight=weight, view=view, shape=shape, min_val=min_val,
+        return dict(runtime=runtime, weight=weight, view=view, shape=shape, min_val=min_val, post=post,
                     per_channel=per_channel, int_thr=self.int_scaling_impl.host_value(bw), qmin=qmin, qmax=qmax,
                     round_mode=iq.float_to_int_impl.bvq_round_mode, clamp_ste=iq.tensor_clamp_impl.bvq_clamp_ste)
 
@@ -246,6 +250,17 @@ class RescalingIntQuant(torch.nn.Module):
             if runtime is not None:
                 runtime.bvq_running_folded = False
             fast = None
+            if tmpl['post'] is not None:
+                if group is not None:
+                    raise NotImplementedError('batch-sharded quantizer with a non-trivial statistic -> scale map')
+                post = tmpl['post']
+                y, scale, stat = _fused.StatsGraphFakeQuantFn.apply(
+                    x, int_threshold, sp, tmpl['qmin'], tmpl['qmax'], tmpl['round_mode'], tmpl['clamp_ste'], pre_op,
+                    post, *tuple(post.parameters()))
+                if runtime is not None:
+                    runtime.update_running_stats(stat)
+                zero_point = self.zero_point_impl(x, scale, bit_width)
+                return y, scale, zero_point, bit_width
             if runtime is None and group is None:  # a weight: the autograd node in C++ when it is built and applies
                 fast = _fused.fast_stats_fakequant(x, int_threshold, sp, tmpl['qmin'], tmpl['qmax'], tmpl['round_mode'],
                                                    tmpl['clamp_ste'], pre_op)

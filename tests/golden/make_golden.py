@@ -835,10 +835,70 @@ def gen_kl():
     st.save()
 
 
+# ------------------------------------------------------------------------------------------------
+# L. affine rescaling of the statistic (_StatsScaling with affine_rescaling=True, B/core/scaling/runtime.py:19-72):
+#    threshold = clamp_min(|stat * affine_weight + affine_bias|); weights and activations, gradients of the two
+#    affine parameters included
+# ------------------------------------------------------------------------------------------------
+def gen_affine():
+    st = Store('affine')
+
+    def set_affine(q):
+        ar = q.scaling_impl.stats_scaling_impl.affine_rescaling
+        with torch.no_grad():
+            ar.affine_weight.copy_(1.0 + 0.25 * torch.randn(ar.affine_weight.shape))
+            ar.affine_bias.copy_(0.05 * torch.randn(ar.affine_bias.shape))
+        return ar
+
+    for dn in ('f32', 'bf16'):
+        shape = (12, 6, 3, 3)
+        w = torch.randn(shape) * 0.05
+        w[4] = 0.0
+        w = torch.nn.Parameter(w.to(DT[dn]))
+        q = RescalingIntQuant(
+            IntQuant(narrow_range=True, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClampSte()),
+            StatsFromParameterScaling(AbsMax(1), OverOutputChannelView(None), 1, [w], FloatRestrictValue(),
+                                      (shape[0], 1, 1, 1), affine_rescaling=True, scaling_min_val=1e-10),
+            IntScaling(signed=True, narrow_range=True), ZeroZeroPoint(), BitWidthConst(8))
+        ar = set_affine(q)
+        y, scale, zp, bwt = q(w)
+        g = torch.randn(y.shape).to(y.dtype)
+        y.backward(g)
+        st.case({'graph': 'weight_affine', 'dtype': dn, 'shape': list(shape)}, x=w.data, g=g, y=y, scale=scale, dx=w.grad,
+                affine_weight=ar.affine_weight.detach(), affine_bias=ar.affine_bias.detach(),
+                daw=ar.affine_weight.grad, dab=ar.affine_bias.grad)
+    for dn in ('f32', 'bf16'):
+        for tag, pc in (('per_tensor', None), ('per_channel', 6)):
+            if pc is None:
+                view, stats, shape = OverTensorView(), AbsMax(), ()
+            else:
+                view, stats, shape = OverOutputChannelView((1, 0, 2, 3)), AbsMax(1), (1, pc, 1, 1)
+            q = RescalingIntQuant(
+                IntQuant(narrow_range=False, signed=True, float_to_int_impl=RoundSte(), tensor_clamp_impl=TensorClamp()),
+                RuntimeStatsScaling(stats, view, FloatRestrictValue(), shape, affine_rescaling=True,
+                                    scaling_stats_momentum=0.1, scaling_min_val=1e-10),
+                IntScaling(signed=True, narrow_range=False), ZeroZeroPoint(), BitWidthConst(8))
+            ar = set_affine(q)
+            q.train()
+            for step in range(2):
+                x = (torch.randn(4, 6, 5, 5) * (1.0 + step)).to(DT[dn])
+                xi = x.clone().requires_grad_(True)
+                q.zero_grad()
+                y, scale, zp, bwt = q(xi)
+                g = torch.randn(y.shape).to(y.dtype)
+                y.backward(g)
+                st.case({'graph': 'act_affine', 'tag': tag, 'dtype': dn, 'step': step, 'channels': pc},
+                        x=x, g=g, y=y, scale=scale, dx=xi.grad,
+                        affine_weight=ar.affine_weight.detach(), affine_bias=ar.affine_bias.detach(),
+                        daw=ar.affine_weight.grad, dab=ar.affine_bias.grad,
+                        running_stats=q.scaling_impl.runtime_stats.running_stats.clone())
+    st.save()
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     only = sys.argv[1:]
-    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point', 'learned_bw', 'moments', 'kl'}:
+    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point', 'learned_bw', 'moments', 'kl', 'affine'}:
         # the first four files were generated in ONE run, in this order, from a single seed
         torch.manual_seed(123456)
         gen_ste()
@@ -869,3 +929,6 @@ if __name__ == '__main__':
     if not only or 'kl' in only:
         torch.manual_seed(123464)
         gen_kl()
+    if not only or 'affine' in only:
+        torch.manual_seed(123465)
+        gen_affine()
