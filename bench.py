@@ -404,6 +404,33 @@ class Measurement:
         return d
 
 
+def probe_sharded_node(group, device):
+    """One tiny step of the batch-sharded quantizer through the C++ autograd node (which issues its collectives
+    through c10d itself) before anything is timed: if it raises on ANY rank, every rank switches the sharded node off
+    for this run and the sharded steps take the Python Function (same kernels, same results, more host time).
+    -> True (node in use) / False (switched off) / None (node not built)"""
+    import brevitas_amd.config as config
+    from brevitas_amd.core.quant import _fused
+    if not _fused._fast_module() or not config.CPP_AUTOGRAD_SHARDED:
+        return None
+    ok = 1.0
+    try:
+        q = build_quantizer(8, True, device, group)
+        x = torch.randn(4, 8, 14, 16, device=device, dtype=torch.bfloat16).requires_grad_(True)
+        y = q(x)[0]
+        y.backward(torch.randn_like(y))
+        torch.cuda.synchronize()
+    except Exception as exc:  # noqa: BLE001
+        sys.stderr.write('bench.py: the sharded C++ node failed its probe (%s); using the Python Function\n' % (exc,))
+        ok = 0.0
+    flag = torch.tensor([ok], device=device)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=group)
+    if float(flag.item()) < 1.0:
+        config.CPP_AUTOGRAD_SHARDED = False
+        return False
+    return True
+
+
 def library_digest():
     """digest of the sources the loaded libbvq.so was built from (brevitas_amd/csrc/build.py's stamp) or None"""
     try:
@@ -479,9 +506,12 @@ def main():
             torch.cuda.empty_cache()
 
     timer = None
+    cpp_sharded = None
     if on_gpu:
         from brevitas_amd import _native as nat
         timer = KernelTimer('bvq_fakequant_bwd', 'bvq_fakequant_fwd', 'bvq_stats', 'bvq_stats_fakequant_fwd')
+        if group is not None:
+            cpp_sharded = probe_sharded_node(group, device)
     settle_target = SETTLE_STEPS if args.settle_steps is None else args.settle_steps
     settle = 0 if args.no_settle else max(0, settle_target - args.warmup)
     has_act = kind in ('act_pc', 'act_pt', 'qconv', 'qlinear')
@@ -588,6 +618,7 @@ def main():
                                     '(AbsMax), IntScaling, ZeroZeroPoint, BitWidthConst), training mode',
                        'parallelism': par,
                        'rccl_ranks': rccl_ranks,
+                       'sharded_autograd_node': {True: 'C++ (collectives issued through c10d from the node)', False: 'Python Function (the C++ node failed its start-up probe)', None: None}[cpp_sharded] if group is not None else None,
                        'algorithmic_bytes_per_elem': m.bytes_per_elem},
             'hbm_frac_whole_step': round(m.bytes_per_elem * m.n_elem * world / (m.ms_per_step * 1e-3) / 1e9
                                          / (HBM_PEAK_GBS * world), 4),

@@ -23,3 +23,6 @@ FUSED_PATHS = _env_flag('BREVITAS_AMD_FUSED', True)
 # the weight quantizer's autograd node in C++ (brevitas_amd/_bvq_autograd.so, host glue over the same C-ABI calls);
 # 0: always the Python torch.autograd.Function
 CPP_AUTOGRAD = _env_flag('BREVITAS_AMD_CPP_AUTOGRAD', True)
+# the batch-sharded form of the activation node, which issues its two collectives through c10d from C++; 0: sharded
+# quantizers take the Python Function (bench.py switches it off for the run if its start-up probe of the node fails)
+CPP_AUTOGRAD_SHARDED = _env_flag('BREVITAS_AMD_CPP_SHARDED', True)

@@ -682,7 +682,7 @@ def fast_act_stats_fakequant(x, int_threshold, sp, qmin, qmax, round_mode, clamp
         return None  # bench.py is bracketing the C-ABI calls of this step with HIP events: keep them visible
     if x.device.index is not None and x.device.index != torch.cuda.current_device():
         return None
-    if group is not None and sp.channels <= 1:
+    if group is not None and (sp.channels <= 1 or not config.CPP_AUTOGRAD_SHARDED):
         return None
     running = None
     momentum, first = 0.0, False

@@ -402,6 +402,58 @@ __global__ __launch_bounds__(kBlock15) void kth_pick_wide_kernel(const uint32_t*
 
 using namespace bvq;
 
+// ---- channel-last layouts (short `inner`): select on a transposed copy -----------------------------------------
+// A per-channel radix select needs a channel's elements together: one private 2048-bin LDS histogram per wave is what
+// makes the first digit pass cheap, and `channels x 2048` counters do not fit on chip for a wave that sees every
+// channel in each row (channel-last [tokens, hidden], NHWC).  Round 2 sent such layouts down the row-mapped route with
+// one-element rows (27 ms for AbsPercentile on [802816,512] bf16).  Round 3: the tensor, seen as a [rows][L = channels *
+// inner] matrix, is transposed once into the caller's workspace -- [L][rows]: a channel's inner * rows elements are
+// contiguous, in another order, which a k-th VALUE does not care about -- and every digit pass reads the copy as
+// (outer = 1, channels, inner * rows).  64 x 64 tiles through LDS, 16-byte loads and stores: one read + one write.
+constexpr int kTile = 64;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void transpose_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t R,
+                                                           int64_t L) {
+  constexpr int VEC = 16 / sizeof(T);              // elements per 16-byte access
+  constexpr int kTPR = kTile / VEC;                // threads per tile row
+  constexpr int kRPI = kBlock / kTPR;              // tile rows per load iteration
+  __shared__ T tile[kTile][kTile + 16 / sizeof(T) / 4 * 2 + 2];  // padded pitch: the column reads below spread over the banks
+  const int64_t r0 = (int64_t)blockIdx.x * kTile, c0 = (int64_t)blockIdx.y * kTile;
+  const int tr = threadIdx.x / kTPR, tc = (threadIdx.x % kTPR) * VEC;
+#pragma unroll
+  for (int i = 0; i < kTile / kRPI; ++i) {
+    const int r = tr + i * kRPI;
+    if (r0 + r < R && c0 + tc < L) {  // (L is a multiple of VEC: a chunk is whole or absent)
+      const vec_t<T, VEC> v = load_vec<T, VEC>(x + (r0 + r) * L + c0 + tc);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) tile[r][tc + k] = v.v[k];
+    }
+  }
+  __syncthreads();
+  // output row (c0 + oc) = tile column oc; a thread writes VEC consecutive original rows of it
+  const bool aligned = (R * (int64_t)sizeof(T)) % 16 == 0;
+#pragma unroll
+  for (int i = 0; i < kTile / kRPI; ++i) {
+    const int oc = tr + i * kRPI, orow = tc;
+    if (c0 + oc >= L || r0 + orow >= R) continue;
+    T* dst = out + (c0 + oc) * R + r0 + orow;
+    if (aligned && r0 + orow + VEC <= R) {
+      vec_t<T, VEC> v;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v.v[k] = tile[orow + k][oc];
+      store_vec<T, VEC>(dst, v);
+    } else {
+      for (int k = 0; k < VEC && r0 + orow + k < R; ++k) dst[k] = tile[orow + k][oc];
+    }
+  }
+}
+
+// the layouts that take the transposed copy, and where it lives in the workspace
+static bool cols_select_applies(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner) {
+  return x && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && cols_plan(dtype, outer, channels, inner).ok;
+}
+
 static int passes_for(int dtype) { return dtype == BVQ_F32 ? 3 : 2; }
 
 // workspace layout (depends on dtype and channels only):
@@ -462,8 +514,14 @@ static int sel_check(const char* who, int dtype, int64_t channels, const void* w
   return BVQ_OK;
 }
 
+// (the transposed copy of a channel-last tensor sits behind the select's own state; sized whether or not x will turn out
+//  16-byte aligned)
+static int64_t sel_scratch_offset(int dtype, int64_t channels) { return (sel_workspace_bytes(dtype, channels) + 255) / 256 * 256; }
+
 extern "C" int64_t bvq_kth_workspace_bytes(int dtype, int64_t outer, int64_t channels, int64_t inner) {
   if (dtype < BVQ_F32 || dtype > BVQ_F16 || outer < 0 || channels < 1 || inner < 0) return -1;
+  if (cols_plan(dtype, outer, channels, inner).ok)
+    return sel_scratch_offset(dtype, channels) + outer * channels * inner * (int64_t)dtype_size(dtype) + 256;
   return sel_workspace_bytes(dtype, channels);
 }
 
@@ -515,6 +573,36 @@ extern "C" int bvq_kth_hist(int abs_key, int dtype, const void* x, int64_t outer
   }
   hipStream_t st = (hipStream_t)stream;
   const SelWorkspace w = sel_workspace(dtype, channels, workspace);
+  if (cols_select_applies(dtype, x, outer, channels, inner)) {
+    // channel-last: pass 0 transposes x into the workspace, every pass reads the copy (outer = 1, inner * outer per channel)
+    const int64_t off = sel_scratch_offset(dtype, channels);
+    const int64_t n_bytes = outer * channels * inner * (int64_t)dtype_size(dtype);
+    if (workspace_bytes < off + n_bytes) {
+      set_error("bvq_kth_hist: workspace %lld < %lld bytes (channel-last layout: bvq_kth_workspace_bytes with the shape)",
+                (long long)workspace_bytes, (long long)(off + n_bytes));
+      return BVQ_ERR_WORKSPACE;
+    }
+    void* copy = reinterpret_cast<char*>(workspace) + off;
+    if (pass == 0) {
+      const int64_t L = channels * inner;
+      const dim3 tg((unsigned)((outer + kTile - 1) / kTile), (unsigned)((L + kTile - 1) / kTile));
+      if (tg.y > 65535) {
+        set_error("bvq_kth_hist: %lld columns exceed the transpose grid", (long long)L);
+        return BVQ_ERR_UNSUPPORTED;
+      }
+      if (dtype == BVQ_F32)
+        transpose_kernel<float><<<tg, dim3(kBlock), 0, st>>>(reinterpret_cast<const float*>(x),
+                                                            reinterpret_cast<float*>(copy), outer, L);
+      else  // bf16 / f16: 2-byte elements move as bit patterns
+        transpose_kernel<uint16_t><<<tg, dim3(kBlock), 0, st>>>(reinterpret_cast<const uint16_t*>(x),
+                                                               reinterpret_cast<uint16_t*>(copy), outer, L);
+      rc = check_launch("bvq_kth_hist/transpose");
+      if (rc) return rc;
+    }
+    x = copy;
+    inner = outer * inner;
+    outer = 1;
+  }
   const int64_t t_outer = channels > 1 ? outer : 1;
   const int64_t row_len = channels > 1 ? inner : outer * inner;
   const int full = 16 / dtype_size(dtype);

@@ -881,6 +881,53 @@ __global__ __launch_bounds__(kBlock) void tie_scan_kernel(Tiling t, const void* 
   }
 }
 
+// the same scan on channel-last layouts (ColsPlan units: a lane owns the VEC columns of its chunk for a block of rows):
+// per column the FIRST row whose element attains the statistic of the column's channel -- per-channel layouts record the
+// first position only -- folded into info[channel] with one atomicMin per hit (rare: a handful per channel); optionally
+// the zero fill of dx on the same read.  (The row-mapped scan degenerates to one-element rows on these layouts.)
+template <typename T, int MATCH, bool WRITE_ZERO>
+__global__ __launch_bounds__(kBlock) void tie_scan_cols_kernel(ColsPlan p, const void* x, const void* stat,
+                                                               unsigned long long* info, void* dx, int64_t inner) {
+  constexpr int VEC = elem<T>::vec;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (unit >= p.units) return;
+  const int64_t rblk = unit / p.strips;
+  const int32_t strip = (int32_t)(unit - rblk * p.strips);
+  const int32_t sub = lane / p.lpr;
+  const int32_t chunk = strip * kWave + (lane - sub * p.lpr);
+  if (!(sub < p.rpp && chunk < p.cps)) return;
+  const int64_t row0 = rblk * p.rb + sub;
+  const int64_t row_end = (rblk + 1) * p.rb < p.rows ? (rblk + 1) * p.rb : p.rows;
+  const T* __restrict__ xp = reinterpret_cast<const T*>(x) + (int64_t)chunk * VEC;
+  T* __restrict__ dp = reinterpret_cast<T*>(dx) + (int64_t)chunk * VEC;
+  T sv[VEC];
+  int64_t first[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    sv[k] = reinterpret_cast<const T*>(stat)[((int64_t)chunk * VEC + k) / inner];
+    first[k] = -1;
+  }
+  for (int64_t r = row0; r < row_end; r += p.rpp) {
+    const vec_t<T, VEC> xv = load_vec<T, VEC>(xp + r * p.L);
+    vec_t<T, VEC> zv;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      zv.v[k] = zero_like<T, MATCH>(xv.v[k]);
+      if (first[k] < 0 && is_tie<T, MATCH>(xv.v[k], sv[k])) first[k] = r;
+    }
+    if (WRITE_ZERO) store_vec<T, VEC>(dp + r * p.L, zv);
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    if (first[k] >= 0) {
+      const int64_t col = (int64_t)chunk * VEC + k;
+      record_tie(info, true, (int32_t)(col / inner), (unsigned long long)(first[k] * inner + col % inner));
+    }
+  }
+}
+
 __global__ void tie_init_kernel(unsigned long long* info, int32_t channels, int first_only) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (channels > 1 || first_only) {
@@ -1829,6 +1876,36 @@ extern "C" int bvq_stat_tie_scan(int match, int dtype, const void* x, const void
   if (!x || !stat) {
     set_error("bvq_stat_tie_scan: null pointer");
     return BVQ_ERR_INVALID;
+  }
+  // channel-last (or nearly) per-channel layouts: column-mapped units
+  const ColsPlan cp = (channels > 1 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx_zero_fill)) & 15) == 0)
+                          ? cols_plan(dtype, outer, channels, inner)
+                          : ColsPlan{};
+  if (cp.ok) {
+    const dim3 grid(grid_for_units(cp.units)), block(kBlock);
+#define BVQ_TSC(T, M)                                                                                        \
+  do {                                                                                                       \
+    if (dx_zero_fill)                                                                                        \
+      tie_scan_cols_kernel<T, M, true><<<grid, block, 0, st>>>(cp, x, stat, info, dx_zero_fill, inner);       \
+    else                                                                                                     \
+      tie_scan_cols_kernel<T, M, false><<<grid, block, 0, st>>>(cp, x, stat, info, nullptr, inner);           \
+  } while (0)
+#define BVQ_TSC_T(T)                      \
+  do {                                    \
+    if (match == BVQ_MATCH_ABS)           \
+      BVQ_TSC(T, BVQ_MATCH_ABS);          \
+    else                                  \
+      BVQ_TSC(T, BVQ_MATCH_VALUE);        \
+  } while (0)
+    if (dtype == BVQ_F32)
+      BVQ_TSC_T(float);
+    else if (dtype == BVQ_BF16)
+      BVQ_TSC_T(bf16_t);
+    else
+      BVQ_TSC_T(f16_t);
+#undef BVQ_TSC_T
+#undef BVQ_TSC
+    return check_launch("bvq_stat_tie_scan/cols");
   }
   int vec;
   const Tiling t = stat_tiling(dtype, x, dx_zero_fill, outer, channels, inner, vec);

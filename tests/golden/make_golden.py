@@ -895,10 +895,51 @@ def gen_affine():
     st.save()
 
 
+# ------------------------------------------------------------------------------------------------
+# M. percentile and moment statistics reduced over dim 0 of [rows, channels] tensors (channel axis LAST: [tokens, hidden],
+#    flattened NHWC) -- the layout the column-mapped kernels serve
+# ------------------------------------------------------------------------------------------------
+def gen_channel_last():
+    from brevitas.core.stats import AbsAve, AbsPercentile, MeanSigmaStd, NegativePercentileOrZero, PercentileInterval
+    st = Store('channel_last')
+    for dn, dtype in DT.items():
+        for tag, shape in (('tokens_hidden', (96, 16)), ('odd_rows', (131, 24)), ('wide', (65, 200))):
+            x = torch.randn(shape) * 2
+            x.view(-1)[::17] = 0.0
+            x[:, 3] = 0.0                       # an all-zero channel
+            x[5, 1] = float('inf')
+            x = x.to(dtype)
+            for q in (99.999, 50.0, 3.0, 100.0):
+                xi = x.clone().requires_grad_(True)
+                out = AbsPercentile(q, 0)(xi)
+                gout = torch.randn(out.shape).to(out.dtype)
+                out.backward(gout)
+                st.case({'stat': 'abs_percentile', 'q': q, 'dim': 0, 'tag': tag, 'dtype': dn}, x=x, out=out, gout=gout,
+                        dx=xi.grad if q in (99.999, 50.0) else None)
+            for q in (0.01, 60.0):
+                st.case({'stat': 'neg_percentile', 'q': q, 'dim': 0, 'tag': tag, 'dtype': dn}, x=x,
+                        out=NegativePercentileOrZero(q, 0)(x))
+            st.case({'stat': 'interval', 'low_q': 0.01, 'high_q': 99.9, 'dim': 0, 'tag': tag, 'dtype': dn}, x=x,
+                    out=PercentileInterval(0.01, 99.9, 0)(x))
+            xf = torch.where(torch.isfinite(x), x, torch.zeros_like(x))
+            xi = xf.clone().requires_grad_(True)
+            out = AbsAve(0)(xi)
+            gout = torch.randn(out.shape).to(out.dtype)
+            out.backward(gout)
+            st.case({'stat': 'abs_ave', 'dim': 0, 'tag': tag, 'dtype': dn}, x=xf, out=out, gout=gout, dx=xi.grad)
+            xi = xf.clone().requires_grad_(True)
+            out = MeanSigmaStd(3.0, 0)(xi)
+            gout = torch.randn(out.shape).to(out.dtype)
+            out.backward(gout)
+            st.case({'stat': 'mean_sigma_std', 'sigma': 3.0, 'dim': 0, 'tag': tag, 'dtype': dn}, x=xf, out=out, gout=gout,
+                    dx=xi.grad)
+    st.save()
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     only = sys.argv[1:]
-    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point', 'learned_bw', 'moments', 'kl', 'affine'}:
+    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point', 'learned_bw', 'moments', 'kl', 'affine', 'channel_last'}:
         # the first four files were generated in ONE run, in this order, from a single seed
         torch.manual_seed(123456)
         gen_ste()
@@ -932,3 +973,6 @@ if __name__ == '__main__':
     if not only or 'affine' in only:
         torch.manual_seed(123465)
         gen_affine()
+    if not only or 'channel_last' in only:
+        torch.manual_seed(123466)
+        gen_channel_last()
