@@ -32,8 +32,10 @@ HEADERS = ['bvq_common.h', 'bvq_quant_math.h', 'bvq_ties.h', 'bvq_sums.h', 'bvq_
 
 # -ffp-contract=off: the reference rounds after every op; a contracted mul+add would not.
 # hipcc's default fp32 division is correctly rounded (no -ffast-math, no approximate reciprocal).
+# --offload-compress: the gfx950 code objects are stored compressed in the fat binary (12.9 -> ~4 MB); the HIP runtime
+# unpacks them when the library's first kernel is launched.
 FLAGS = [
-    '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math',
+    '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math', '--offload-compress',
     '-Wall', '-Wno-unused-function', '-Wno-sometimes-uninitialized', '-Wno-uninitialized',
     '-Wno-unused-variable']
 

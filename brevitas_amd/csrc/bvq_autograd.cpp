@@ -287,7 +287,14 @@ class ActStatsFakeQuant : public torch::autograd::Function<ActStatsFakeQuant> {
     ctx->saved_data["shape"] = p.shape;
     if (sharded) {
       const std::string name = p.group->getGroupName();
-      if (!groups().count(name)) groups()[name] = GroupRef{p.group, new py::object(p.py_group)};
+      // names come back after destroy_process_group / init_process_group: the entry follows the live group
+      auto it = groups().find(name);
+      if (it == groups().end()) {
+        groups()[name] = GroupRef{p.group, new py::object(p.py_group)};
+      } else if (it->second.pg != p.group) {
+        it->second.pg = p.group;
+        *it->second.py = p.py_group;
+      }
       ctx->saved_data["group"] = name;
     }
     at::Tensor scale_out = scale.view(p.shape), stat_out = stat.view(p.shape);

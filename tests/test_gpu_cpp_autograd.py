@@ -147,11 +147,13 @@ def test_cpp_activation_node_sharded_world_of_one(monkeypatch):
     os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
     sock.close()
     torch.cuda.set_device(0)
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
-    try:
-        _sharded_world_of_one(monkeypatch, dist, build_quantizer, _fused)
-    finally:
-        dist.destroy_process_group()
+    # twice: the second default group has the first one's name and another communicator -- the node must follow it
+    for _ in range(2):
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+        try:
+            _sharded_world_of_one(monkeypatch, dist, build_quantizer, _fused)
+        finally:
+            dist.destroy_process_group()
 
 
 def _sharded_world_of_one(monkeypatch, dist, build_quantizer, _fused):
