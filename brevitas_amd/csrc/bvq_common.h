@@ -319,7 +319,9 @@ struct ColsPlan {
   int64_t units;    // nrb * strips
 };
 // no_partials: the caller's kernel writes no per-unit partial rows (more, shorter units pay then)
-ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bool no_partials = false);
+// team: the caller's kernel gives a unit to a whole workgroup (four waves sharing the rows, partials combined on chip)
+ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bool no_partials = false,
+                   bool team = false);
 
 static inline unsigned grid_for_units(int64_t units) {
   return (unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock);

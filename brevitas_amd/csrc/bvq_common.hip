@@ -125,7 +125,7 @@ int env_flag(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bool no_partials) {
+ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bool no_partials, bool team) {
   static const int enabled = env_flag("BVQ_COLS", 1);
   ColsPlan p = {};
   const int el = dtype == BVQ_F32 ? 4 : 2;
@@ -157,10 +157,25 @@ ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bo
   }();
   // (a kernel that leaves no partial rows behind -- the forward -- is faster with 8 x the units: 4.99 -> 5.70 TB/s
   //  on [802816,512] bf16; with partial rows the extra traffic and the longer fold eat the gain)
-  const int want_units = env_units ? env_units : (no_partials ? 65536 : 8192);
+  // (team units are workgroups of four waves: the same 65536 waves without partials, 32768 waves with them -- a
+  //  workgroup leaves ONE partial row behind, so four times the waves cost no more partial traffic)
+  // (read-only kernels with partial rows -- abs-max, min/max, moments: 4096 waves, one resident round of four per SIMD,
+  //  measured 7-13 % faster than 8192 on every layout; 2048 and fewer starve the memory system)
+  const int want_units = env_units ? env_units : (no_partials ? (team ? 16384 : 65536) : (team ? 8192 : 4096));
   const int64_t want_blocks = want_units / p.strips > 0 ? want_units / p.strips : 1;
   const int64_t rows_for_that = (outer + want_blocks - 1) / want_blocks;
   if (rows_for_that > rb) rb = ((rows_for_that + p.rpp - 1) / p.rpp) * p.rpp;
+  if (team && !no_partials && !env_units) {
+    // a workgroup's rows by count, not by a unit total: short blocks keep the resident workgroups' window of memory
+    // small, which is what these kernels' bandwidth follows (profiles/r03_column_mapped.txt: 16-bit types best at
+    // 64..128 rows on every layout measured, float32 at 16..48) -- down to where a wave's set-up (its columns' scales,
+    // reciprocals) stops being hidden: the 16-bit kernel holds 8 columns per lane in ~100 registers, four waves per
+    // SIMD, and falls off below ~12 rows per wave; the float32 one runs seven waves.
+    // One partial row of 4 L bytes per block: 1/96 (1/16) of a block's 3 x 2 L (3 x 4 L) bytes per row = 0.7 % (2 %).
+    static const int env_rows = env_flag("BVQ_COLS_TEAM_ROWS", 0);  // experiments only
+    const int64_t groups = env_rows > 0 ? env_rows : (el == 2 ? 96 : 16);
+    rb = groups * (int64_t)p.rpp;
+  }
   // a lane's row counter within a unit fits 16 bits (the backward packs it next to a 16-bit key)
   if (rb > 65000 * (int64_t)p.rpp) rb = 65000 * (int64_t)p.rpp;
   // a unit's byte extent fits the 32-bit offsets of a buffer descriptor (the backward addresses it that way)

@@ -254,23 +254,27 @@ template <typename T>
 struct ColsLane {
   static constexpr int VEC = elem<T>::vec;
   int64_t row0, row_end;
+  int64_t blk0;  // first row of the unit's row block (wave-uniform)
   int32_t chunk, sub;
   bool active;
   int32_t ch[VEC];
   f2 s2[VEC / 2], z2[VEC / 2];
   bool fast, zp0;  // wave-uniform: every column's scale suits the bf16 reciprocal / every zero-point is +0
 
-  __device__ __forceinline__ bool init(const ColsQuantArgs& a) {
+  // team: the unit is the WORKGROUP's -- its waves take the block's rows in turn (wave w: rows w, w + 4, ... of each
+  // lane group), so that the workgroup walks one contiguous window of memory, and combine their partials on chip
+  __device__ __forceinline__ bool init(const ColsQuantArgs& a, bool team = false) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    const int64_t unit = team ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * kWavesPerBlock + wave;
     if (unit >= a.p.units) return false;
     const int64_t rblk = unit / a.p.strips;
     const int32_t strip = (int32_t)(unit - rblk * a.p.strips);
     sub = lane / a.p.lpr;
     chunk = strip * kWave + (lane - sub * a.p.lpr);
     active = sub < a.p.rpp && chunk < a.p.cps;
-    row0 = rblk * a.p.rb + sub;
+    blk0 = rblk * a.p.rb;
+    row0 = blk0 + (team ? (int64_t)wave * a.p.rpp : 0) + sub;
     row_end = (rblk + 1) * a.p.rb < a.p.rows ? (rblk + 1) * a.p.rb : a.p.rows;
     bool ok_fast = true, ok_zp0 = true;
     float sv[VEC], zv[VEC];
@@ -366,13 +370,13 @@ static void fill_args(QuantArgs& a, const bvq_quant_desc* d) {
 
 // column-mapped route for this call? (channel axis last or nearly last; see ColsPlan)
 static ColsPlan cols_quant_plan(const bvq_quant_desc* d, const void* p0, const void* p1, const void* p2,
-                                bool no_partials = false) {
+                                bool no_partials = false, bool team = false) {
   ColsPlan none = {};
   if (!(d->scale_per_channel && d->channels > 1) || d->x_dtype != d->ct_dtype || d->out_kind != BVQ_OUT_DEQUANT)
     return none;
   if ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15)
     return none;
-  return cols_plan(d->x_dtype, d->outer, d->channels, d->inner, no_partials);
+  return cols_plan(d->x_dtype, d->outer, d->channels, d->inner, no_partials, team);
 }
 
 static void fill_cols_args(ColsQuantArgs& a, const ColsPlan& cp, const bvq_quant_desc* d) {
@@ -390,9 +394,11 @@ static void fill_cols_args(ColsQuantArgs& a, const ColsPlan& cp, const bvq_quant
   a.pre_relu = d->pre_op == BVQ_PRE_RELU;
 }
 
-#define BVQ_COLS_LAUNCH(KERNEL, a, nt, st)                                                       \
+#define BVQ_COLS_LAUNCH(KERNEL, a, nt, st) BVQ_COLS_LAUNCH_G(KERNEL, a, nt, st, grid_for_units((a).p.units))
+// GRID workgroups (a kernel whose unit is the workgroup passes the plan's unit count)
+#define BVQ_COLS_LAUNCH_G(KERNEL, a, nt, st, GRID)                                               \
   do {                                                                                           \
-    const dim3 grid(grid_for_units((a).p.units)), block(kBlock);                                 \
+    const dim3 grid((unsigned)(GRID)), block(kBlock);                                            \
     const bool rne = (a).round_mode == BVQ_ROUND;                                                \
     if (d->x_dtype == BVQ_F32) {                                                                 \
       if (rne && nt) KERNEL<float, BVQ_ROUND, true><<<grid, block, 0, st>>>(a);                  \

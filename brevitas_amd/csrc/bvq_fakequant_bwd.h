@@ -548,42 +548,54 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96), amdgpu_
 #define BVQ_COLS_BWD_WAVES 4  // occupancy floor handed to the register allocator
 #endif
 
-template <typename T, int RM, bool NT, bool ZP0, bool FAST>
-__device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const ColsLane<T>& ln, float qmin, float qmax) {
+// One wave's unit of the column-mapped backward: a block of rows of its strip of 64 column chunks.  The block is
+// addressed through buffer descriptors (base = the block's first row, extent = its bytes; cols_plan keeps that below
+// 2^31): a lane's rows are offset, offset + step, ... and rows past the block's end read zeros without a memory access
+// and drop their stores -- the walk has no execution mask and no 64-bit address arithmetic (the first form of this
+// kernel spent 40 of its 243 vector instructions per row on both).  PRE (the fused ReLU) is a template parameter for
+// the same reason: as a run-time flag it cost five selects per pair.
+// Arg-max search of the statistic: the hot loop keeps each column's largest |x| key only (packed unsigned 16-bit max:
+// 2 instructions per pair); a lane one of whose columns attains its channel's statistic -- about one lane per channel
+// in the whole launch -- walks its rows once more, cold, and takes the first row that shows it.
+template <typename T, int RM, bool NT, bool ZP0, bool FAST, bool PRE>
+__device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const ColsLane<T>& ln, float qmin, float qmax,
+                                              float* sh_ds) {
   constexpr int VEC = elem<T>::vec;
-  constexpr int kU = BVQ_COLS_BWD_UNROLL;
   constexpr bool kSame16 = sizeof(T) == 2;
-  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + (int64_t)ln.chunk * VEC;
-  const T* __restrict__ gp = reinterpret_cast<const T*>(a.g) + (int64_t)ln.chunk * VEC;
-  T* __restrict__ dxp = reinterpret_cast<T*>(a.y) + (int64_t)ln.chunk * VEC;
-  f2 r2[VEC / 2], ds2[VEC / 2], dz_unused = splat2(0.f);
-  // abs-max tie search: per column, the largest |x| key and the first row that showed it.
-  // 16-bit types: one 32-bit word per column, key << 16 | (0xffff - row counter), so that a single unsigned
-  // max keeps both (ColsPlan bounds a lane's rows per unit by 65535).  float32: strictly-greater updates of
-  // (key, row).  A column whose key equals its channel's statistic reports that row.
   typedef short i16x2 __attribute__((ext_vector_type(2)));
-  uint32_t um[VEC], first[kSame16 ? 1 : VEC];
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const int64_t nrows = ln.row_end - ln.blk0;  // wave-uniform, > 0
+  const uint32_t bytes = (uint32_t)(nrows * a.p.L * (int64_t)sizeof(T));
+  const buf_t bx = make_buf(reinterpret_cast<const T*>(a.x) + ln.blk0 * a.p.L, bytes);
+  const buf_t bg = make_buf(reinterpret_cast<const T*>(a.g) + ln.blk0 * a.p.L, bytes);
+  const buf_t bd = make_buf(reinterpret_cast<T*>(a.y) + ln.blk0 * a.p.L, bytes);
+  // the workgroup's waves take the block's row groups in turn: wave w works on groups w, w + 4, ...
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t stride_rows = (int64_t)kWavesPerBlock * a.p.rpp;
+  const uint32_t step = (uint32_t)(stride_rows * a.p.L * (int64_t)sizeof(T));  // between a lane's consecutive rows
+  const uint32_t off0 = (uint32_t)(((ln.row0 - ln.blk0) * a.p.L + (int64_t)ln.chunk * VEC) * (int64_t)sizeof(T));
+  const int64_t mine = nrows - (int64_t)wave * a.p.rpp;  // rows from this wave's first group on
+  const int32_t steps = mine > 0 ? (int32_t)((mine + stride_rows - 1) / stride_rows) : 0;  // the last possibly past the end
+  f2 r2[VEC / 2], ds2[VEC / 2], dz_unused = splat2(0.f);
+  uint32_t um[kSame16 ? VEC / 2 : VEC];  // largest |x| key per column (16-bit types: two keys per word)
 #pragma unroll
   for (int k = 0; k < VEC / 2; ++k) {
     r2[k] = f2{1.0f / ln.s2[k].x, 1.0f / ln.s2[k].y};
     ds2[k] = splat2(0.f);
   }
 #pragma unroll
-  for (int k = 0; k < VEC; ++k) um[k] = 0u;
-#pragma unroll
-  for (int k = 0; k < (kSame16 ? 1 : VEC); ++k)
-    first[k] = ln.row0 < ln.row_end ? (uint32_t)ln.row0 : ~0u;  // an all-zero column attains its 0 in the first row
+  for (int k = 0; k < (kSame16 ? VEC / 2 : VEC); ++k) um[k] = 0u;
   const bool ties = a.tie_stat != nullptr;
   const bool clamp_ste = a.clamp_ste != 0;
   const int mode = a.round_mode;
-  // the work on one row of this lane's columns: rr = the row, cnt = how many rows this lane has seen before it
   const DotSel dsel = make_dot_sel();
-  auto row_work = [&](const vec_t<T, VEC>& xr, const vec_t<T, VEC>& gr, int64_t rr, uint32_t cnt) {
+  // the work on one row of this lane's columns
+  auto row_work = [&](const vec_t<T, VEC>& xr, const vec_t<T, VEC>& gr, uint32_t off) {
     vec_t<T, VEC> dv;
 #pragma unroll
     for (int k = 0; k < VEC; k += 2) {
       const f2 xraw = widen2<T>(xr.v[k], xr.v[k + 1]);
-      const f2 xin = a.pre_relu ? relu2(xraw) : xraw;
+      const f2 xin = PRE ? relu2(xraw) : xraw;
       const f2 gf = widen2<T>(gr.v[k], gr.v[k + 1]);
       f2 d;
       if constexpr (FAST && elem<T>::id == BVQ_F16)
@@ -595,107 +607,144 @@ __device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const Cols
       else
         d = bwd_elem2<T, RM, kBwdDs, ZP0, kSame16>(xin, gf, DivExactV{ln.s2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin,
                                                    qmax, clamp_ste, mode, ds2[k / 2], dz_unused, dz_unused, dsel);
-      if (a.pre_relu) d = xraw > splat2(0.f) ? d : splat2(0.f);
+      if constexpr (PRE) d = xraw > splat2(0.f) ? d : splat2(0.f);  // torch.relu backward: grad * (x > 0)
       pack2<T>(d, dv.v[k], dv.v[k + 1]);
     }
-    store_vec<T, VEC, NT>(dxp + rr * a.p.L, dv);
+    buf_store<T, VEC, NT>(bd, off, dv);  // dropped past the block's end
     if (ties) {
       if constexpr (kSame16) {
         const vec_t<uint32_t, VEC / 2> w = __builtin_bit_cast(vec_t<uint32_t, VEC / 2>, xr);
-        const uint32_t inv = 0xffffu - cnt;
 #pragma unroll
         for (int k = 0; k < VEC / 2; ++k) {
-          // relu: negative patterns (sign bit set) count as 0; otherwise the sign bits are masked below
-          const uint32_t w2 = a.pre_relu ? __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
-                                               __builtin_bit_cast(i16x2, w.v[k]), i16x2{0, 0}))
-                                         : w.v[k];
-          const uint32_t klo = ((w2 << 16) & 0x7fff0000u) | inv, khi = (w2 & 0x7fff0000u) | inv;
-          um[2 * k] = klo > um[2 * k] ? klo : um[2 * k];
-          um[2 * k + 1] = khi > um[2 * k + 1] ? khi : um[2 * k + 1];
+          // relu: negative patterns (sign bit set) count as 0; then both sign bits are cleared (NaN keys stay above inf)
+          const uint32_t w2 = PRE ? __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w.v[k]),
+                                                                                      i16x2{0, 0}))
+                                  : w.v[k];
+          um[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, um[k]),
+                                                                         __builtin_bit_cast(u16x2, w2 & 0x7fff7fffu)));
         }
       } else {
-        const uint32_t rr32 = (uint32_t)rr;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          const uint32_t b = a.pre_relu ? pre_abs_bits<T, true>(xr.v[k]) : pre_abs_bits<T, false>(xr.v[k]);
-          const bool gt = b > um[k];
-          um[k] = gt ? b : um[k];
-          first[k] = gt ? rr32 : first[k];
+          const uint32_t b = pre_abs_bits<T, PRE>(xr.v[k]);
+          um[k] = b > um[k] ? b : um[k];
         }
       }
     }
   };
-  // (a software-pipelined walk like the row-mapped backward's was measured here: with this kernel's per-column state it
-  //  spills at depth 4 and is within +-2 % of these batches at depth 2-3 with a lower occupancy floor, 10 % slower for
-  //  float32: profiles/r02_column_mapped.txt)
-  uint32_t it = 0;  // row counter of this lane (wave-uniform)
-  for (int64_t r = ln.row0; r < ln.row_end; r += (int64_t)kU * a.p.rpp) {
-    vec_t<T, VEC> xv[kU], gv[kU];
-    bool ok[kU];
+  uint32_t off = off0;
+  {
+    constexpr int kU = BVQ_COLS_BWD_UNROLL;
+    for (int32_t i = 0; i < steps; i += kU) {
+      vec_t<T, VEC> xv[kU], gv[kU];
 #pragma unroll
-    for (int j = 0; j < kU; ++j) {
-      const int64_t rr = r + (int64_t)j * a.p.rpp;
-      ok[j] = rr < ln.row_end;
-      const int64_t lo = (ok[j] ? rr : ln.row0) * a.p.L;
-      xv[j] = load_vec<T, VEC, NT>(xp + lo);
-      gv[j] = load_vec<T, VEC, NT>(gp + lo);
+      for (int j = 0; j < kU; ++j) {
+        xv[j] = buf_load<T, VEC, NT>(bx, off + (uint32_t)j * step);
+        gv[j] = buf_load<T, VEC, NT>(bg, off + (uint32_t)j * step);
+      }
+#pragma unroll
+      for (int j = 0; j < kU; ++j)
+        if (i + j < steps) row_work(xv[j], gv[j], off + (uint32_t)j * step);  // wave-uniform
+      off += (uint32_t)kU * step;
     }
-#pragma unroll
-    for (int j = 0; j < kU; ++j)
-      if (ok[j]) row_work(xv[j], gv[j], r + (int64_t)j * a.p.rpp, it + (uint32_t)j);
-    it += kU;
   }
-  // this lane's partial row of the [prows][L] arrays
-  const int64_t prow = (ln.row0 - ln.sub) / a.p.rb * a.p.rpp + ln.sub;
+  // the workgroup's partial row of the [prows][L] array: the four waves' sums of a column, added in wave order
+  const int64_t prow = ln.blk0 / a.p.rb * a.p.rpp + ln.sub;
   const int64_t base = prow * a.p.L + (int64_t)ln.chunk * VEC;
-  if (a.ds_part) {
+  if (a.ds_part) {  // (wave-uniform; every wave of the workgroup gets here -- lane 0 of a wave is always active)
+    const int lane = threadIdx.x & 63;
+    if (wave > 0) {
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) a.ds_part[base + k] = (k & 1) ? ds2[k / 2].y : ds2[k / 2].x;
+      for (int k = 0; k < VEC; ++k) sh_ds[(wave - 1) * 8 * kWave + k * kWave + lane] = (k & 1) ? ds2[k / 2].y : ds2[k / 2].x;
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        float acc = (k & 1) ? ds2[k / 2].y : ds2[k / 2].x;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock - 1; ++w) acc += sh_ds[w * 8 * kWave + k * kWave + lane];
+        a.ds_part[base + k] = acc;
+      }
+    }
   }
   if (!ties) return;
+  // columns whose largest key is their channel's statistic (a lane without rows has seen nothing)
+  uint32_t sk[VEC], frow[VEC];
+  bool hit[VEC], any = false;
+  const bool has_rows = ln.row0 < ln.row_end;
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
     const int64_t col = (int64_t)ln.chunk * VEC + k;
-    const uint32_t sk = abs_bits<T>(reinterpret_cast<const T*>(a.tie_stat)[col / a.inner]);
-    bool hit;
-    unsigned long long row;
+    sk[k] = abs_bits<T>(reinterpret_cast<const T*>(a.tie_stat)[col / a.inner]);
+    uint32_t key;
     if constexpr (kSame16) {
-      // (low half 0: no row seen; an all-zero column records its first row, 0 | 0xffff > 0)
-      const uint32_t k16 = um[k] >> 16;
-      hit = (elem<T>::id == BVQ_BF16 ? (k16 << 16) : k16) == sk && (um[k] & 0xffffu) != 0u;
-      row = (unsigned long long)ln.row0 + (unsigned long long)(0xffffu - (um[k] & 0xffffu)) * (unsigned long long)a.p.rpp;
+      const uint32_t k16 = (k & 1) ? (um[k / 2] >> 16) : (um[k / 2] & 0xffffu);
+      key = elem<T>::id == BVQ_BF16 ? (k16 << 16) : k16;
     } else {
-      hit = um[k] == sk && first[k] != ~0u;
-      row = first[k];
+      key = um[k];
     }
-    const unsigned long long pos = hit ? row * (unsigned long long)a.inner + (unsigned long long)(col % a.inner) : ~0ull;
-    if (a.pos_part) a.pos_part[base + k] = pos;
-    else if (pos != ~0ull) atomicMin(&a.tie_info[col / a.inner], pos);
+    hit[k] = has_rows && key == sk[k];
+    any = any || hit[k];
+    frow[k] = ~0u;
+  }
+  if (any) {
+    // cold: the first of this lane's rows showing the statistic, four rows in flight (rows past the end read zeros --
+    // they can only match a statistic of 0, which the lane's first row has matched before)
+    uint32_t o = off0;
+    for (int32_t i = 0; i < steps; i += 4) {
+      vec_t<T, VEC> xr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xr[j] = buf_load<T, VEC, false>(bx, o + (uint32_t)j * step);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+          if (hit[k] && frow[k] == ~0u && pre_abs_bits<T, PRE>(xr[j].v[k]) == sk[k]) frow[k] = (uint32_t)(i + j);
+      }
+      o += 4u * step;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int64_t col = (int64_t)ln.chunk * VEC + k;
+    const unsigned long long row = (unsigned long long)ln.row0 + (unsigned long long)frow[k] * (unsigned long long)stride_rows;
+    const unsigned long long pos =
+        hit[k] && frow[k] != ~0u ? row * (unsigned long long)a.inner + (unsigned long long)(col % a.inner) : ~0ull;
+    // pos_part: one entry per column here (initialised to ~0 by the host side), tie_info: one per channel
+    if (pos != ~0ull) atomicMin(a.pos_part ? &a.pos_part[col] : &a.tie_info[col / a.inner], pos);
   }
 }
 
 template <typename T, int RM, bool NT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BVQ_COLS_BWD_WAVES, 8))) void fakequant_bwd_cols_kernel(
     ColsQuantArgs a) {
+  __shared__ float sh_ds[(kWavesPerBlock - 1) * 8 * kWave];  // waves 1..3 hand their column sums to wave 0
   ColsLane<T> ln;
-  if (!ln.init(a) || !ln.active) return;
+  if (!ln.init(a, true) || !ln.active) return;
   const float qmin = rnd<T>(a.qmin), qmax = rnd<T>(a.qmax);
+#define BVQ_COLS_BWD(ZP0, FAST)                                   \
+  do {                                                            \
+    if (a.pre_relu)                                               \
+      cols_bwd_rows<T, RM, NT, ZP0, FAST, true>(a, ln, qmin, qmax, sh_ds);  \
+    else                                                          \
+      cols_bwd_rows<T, RM, NT, ZP0, FAST, false>(a, ln, qmin, qmax, sh_ds); \
+  } while (0)
   if constexpr (sizeof(T) == 2) {
     if (ln.fast) {
       if (ln.zp0)
-        cols_bwd_rows<T, RM, NT, true, true>(a, ln, qmin, qmax);
+        BVQ_COLS_BWD(true, true);
       else
-        cols_bwd_rows<T, RM, NT, false, true>(a, ln, qmin, qmax);
+        BVQ_COLS_BWD(false, true);
       return;
     }
-  }
-  if constexpr (sizeof(T) == 2) {
     if (ln.zp0) {
-      cols_bwd_rows<T, RM, NT, true, false>(a, ln, qmin, qmax);
+      BVQ_COLS_BWD(true, false);
       return;
     }
   }
-  cols_bwd_rows<T, RM, NT, false, false>(a, ln, qmin, qmax);
+  BVQ_COLS_BWD(false, false);
+#undef BVQ_COLS_BWD
 }
 
 // Finish of the stats-scaled backward in ONE launch (per-channel layouts): per channel, sum the units'

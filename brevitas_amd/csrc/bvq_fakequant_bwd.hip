@@ -39,7 +39,7 @@ extern "C" int64_t bvq_fakequant_bwd_workspace_bytes(const bvq_quant_desc* d) {
   const int64_t units = bwd_units(d);
   const int64_t mid = channel_sums_mid_bytes(units / channels + 1, channels) + 16;
   int64_t bytes = 3 * units * (int64_t)sizeof(float) + mid + 256;  // (a third partial array: bvq_fakequant_bwd_bounds)
-  const ColsPlan cp = cols_quant_plan(d, nullptr, nullptr, nullptr);
+  const ColsPlan cp = cols_quant_plan(d, nullptr, nullptr, nullptr, false, true);
   if (cp.ok && (cp.prows + cols_fold_scratch_rows(cp.prows)) * cp.L * (int64_t)sizeof(float) + 256 > bytes)
     bytes = (cp.prows + cols_fold_scratch_rows(cp.prows)) * cp.L * (int64_t)sizeof(float) + 256;
   return bytes;
@@ -86,7 +86,7 @@ static int fakequant_bwd_impl(const bvq_quant_desc* d, const void* g, const void
     return BVQ_ERR_UNSUPPORTED;
   }
   if (!dzp && !bounds) {
-    const ColsPlan cp = cols_quant_plan(d, x, g, dx, !dscale && !tie_stat);
+    const ColsPlan cp = cols_quant_plan(d, x, g, dx, !dscale && !tie_stat, true);
     if (cp.ok) {
       const int64_t need = dscale ? (cp.prows + cols_fold_scratch_rows(cp.prows)) * cp.L * (int64_t)sizeof(float) : 0;
       if (dscale && (!workspace || workspace_bytes < need)) {
@@ -104,7 +104,7 @@ static int fakequant_bwd_impl(const bvq_quant_desc* d, const void* g, const void
       ca.tie_stat = tie_stat;
       ca.tie_info = reinterpret_cast<unsigned long long*>(tie_info);
       const bool cnt = n * (int64_t)(3 * dtype_size(d->x_dtype)) >= nt_threshold_bytes();
-      BVQ_COLS_LAUNCH(fakequant_bwd_cols_kernel, ca, cnt, st);
+      BVQ_COLS_LAUNCH_G(fakequant_bwd_cols_kernel, ca, cnt, st, cp.units);
       rc = check_launch("bvq_fakequant_bwd/cols");
       if (rc) return rc;
       if (dscale) {
@@ -215,8 +215,8 @@ extern "C" int bvq_fakequant_bwd_learned(const bvq_quant_desc* d, const void* g,
 
 static bool bwd_stats_supported(const bvq_quant_desc* d, int64_t& units, int64_t& per_channel) {
   if (!(d->scale_per_channel && d->channels > 1) || d->zp_per_channel) return false;
-  const ColsPlan cp = cols_quant_plan(d, nullptr, nullptr, nullptr);
-  if (cp.ok) {  // column-mapped partials: [prows][L] plus their fold [L]
+  const ColsPlan cp = cols_quant_plan(d, nullptr, nullptr, nullptr, false, true);
+  if (cp.ok) {  // column-mapped partials: [prows][L] plus their fold [L]; first positions [L]
     units = (cp.prows + cols_fold_scratch_rows(cp.prows)) * cp.L;
     per_channel = d->inner;
     return true;
@@ -230,6 +230,9 @@ extern "C" int64_t bvq_fakequant_bwd_stats_workspace_bytes(const bvq_quant_desc*
   if (validate(d)) return -1;
   int64_t units, per_channel;
   if (!bwd_stats_supported(d, units, per_channel)) return 0;  // use bvq_fakequant_bwd + bvq_stat_tie_apply_dscale
+  const ColsPlan cp = cols_quant_plan(d, nullptr, nullptr, nullptr, false, true);
+  if (cp.ok)  // float partial rows and their fold, then one first position per column
+    return units * (int64_t)sizeof(float) + cp.L * (int64_t)sizeof(unsigned long long) + 256;
   return units * (int64_t)(sizeof(float) + sizeof(unsigned long long)) + 256;
 }
 
@@ -361,8 +364,8 @@ static int bwd_stats_impl(const bvq_quant_desc* d, const void* g, const void* x,
   const bool nt =
       n * (int64_t)(2 * dtype_size(d->x_dtype) + dtype_size(d->ct_dtype)) >= nt_threshold_bytes();
   {
-    const ColsPlan cp = cols_quant_plan(d, x, g, dx);
-    const ColsPlan sized = cols_quant_plan(d, nullptr, nullptr, nullptr);
+    const ColsPlan cp = cols_quant_plan(d, x, g, dx, false, true);
+    const ColsPlan sized = cols_quant_plan(d, nullptr, nullptr, nullptr, false, true);
     if (sized.ok && !cp.ok) {
       set_error("bvq_fakequant_bwd_stats: the column-mapped route needs 16-byte aligned x, g and dx");
       return BVQ_ERR_UNSUPPORTED;
@@ -370,7 +373,7 @@ static int bwd_stats_impl(const bvq_quant_desc* d, const void* g, const void* x,
     if (cp.ok) {
       const int64_t words = (cp.prows + cols_fold_scratch_rows(cp.prows)) * cp.L;
       const int64_t pos_off_c = ((words * (int64_t)sizeof(float) + 7) / 8) * 8;
-      if (workspace_bytes < pos_off_c + words * (int64_t)sizeof(unsigned long long)) {
+      if (workspace_bytes < pos_off_c + cp.L * (int64_t)sizeof(unsigned long long)) {
         set_error("bvq_fakequant_bwd_stats: workspace too small");
         return BVQ_ERR_WORKSPACE;
       }
@@ -382,15 +385,17 @@ static int bwd_stats_impl(const bvq_quant_desc* d, const void* g, const void* x,
       ca.scale = scale;
       ca.zp = zp;
       ca.ds_part = reinterpret_cast<float*>(workspace);
+      // first positions attaining the statistic: one entry per column, taken by atomic min from the few lanes that see it
       ca.pos_part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + pos_off_c);
       ca.tie_stat = stat;
-      BVQ_COLS_LAUNCH(fakequant_bwd_cols_kernel, ca, nt, st);
+      launch_tie_init(ca.pos_part, cp.L, st);
+      BVQ_COLS_LAUNCH_G(fakequant_bwd_cols_kernel, ca, nt, st, cp.units);
       rc = check_launch("bvq_fakequant_bwd_stats/cols");
       if (rc) return rc;
       float* ds_fold = nullptr;
-      unsigned long long* pos_fold = nullptr;
-      launch_cols_fold_sum_min(ca.ds_part, ca.pos_part, cp.prows, cp.L, ca.ds_part + cp.prows * cp.L,
-                               ca.pos_part + cp.prows * cp.L, &ds_fold, &pos_fold, st);
+      unsigned long long* pos_fold = ca.pos_part;
+      launch_cols_fold_sum_min(ca.ds_part, nullptr, cp.prows, cp.L, ca.ds_part + cp.prows * cp.L, nullptr, &ds_fold,
+                               nullptr, st);
       if (shard) {  // this shard's all-gather message from the folded partials: one wave per channel
         QuantArgs fa = {};
         fa.t.nob = 1;
