@@ -43,7 +43,7 @@ EXPORTS = (
     'bvq_kthw_plan', 'bvq_kthw_begin', 'bvq_kthw_hist', 'bvq_kthw_pick', 'bvq_kthw_finish',
     'bvq_absmax_onepass_supported', 'bvq_absmax_scale_onepass', 'bvq_fakequant_bwd_stats_onepass_supported',
     'bvq_fakequant_bwd_stats_onepass', 'bvq_scale_from_stat_running', 'bvq_fakequant_bwd_shard',
-    'bvq_shard_unpack_deposit')
+    'bvq_shard_unpack_deposit', 'bvq_absmax_list_supported', 'bvq_absmax_scale_list')
 
 
 class QuantDesc(ctypes.Structure):
@@ -106,6 +106,8 @@ def _load(path=None, strict=True):
         'bvq_absmax_scale_running': (i32, [i32, i32, vp, i64, i64, i64, vp, dbl, i32, dbl, i32, vp, i32, vp, dbl, i32, vp, i64, vp]),
         'bvq_absmax_onepass_supported': (i32, [i32, vp, i64, i64, i64]),
         'bvq_absmax_scale_onepass': (i32, [i32, i32, vp, i64, i64, i64, i32, vp, dbl, i32, dbl, i32, vp, i32, vp, dbl, i32, vp, i64, vp]),
+        'bvq_absmax_list_supported': (i32, [i32, i32, vp, vp, i64, vp]),
+        'bvq_absmax_scale_list': (i32, [i32, i32, vp, vp, i64, vp, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
         'bvq_running_stats_update': (i32, [i32, vp, i32, vp, i64, dbl, i32, vp]),
         'bvq_scale_from_stat': (i32, [vp, i64, i32, vp, dbl, i32, dbl, i32, vp, vp]),
         'bvq_scale_from_stat_running': (i32, [vp, i64, i32, vp, dbl, i32, dbl, i32, vp, i32, vp, dbl, i32, vp]),
@@ -421,6 +423,33 @@ def stats_fakequant_fwd(desc, x, min_val, int_threshold, scale_dtype):
         if _timer is not None:
             _timer.after('bvq_stats_fakequant_fwd')
     return stat, scale, y
+
+
+def absmax_scale_list(xs, outers, channels, inners, min_val, int_threshold, scale_dtype):
+    """abs-max statistic of a LIST of contiguous tensors [outers[i], channels, inners[i]] (the concatenation the
+    reference builds is never materialised) and the scale derived from it, ONE launch:
+    -> (stat [channels], scale [channels]), or None when the list is not covered / no arrival buffer"""
+    dev = require_device(*xs)
+    n = len(xs)
+    dt = dtype_code(xs[0].dtype)
+    for x, o, i in zip(xs, outers, inners):
+        assert x.is_contiguous() and x.dtype == xs[0].dtype and x.numel() == o * channels * i
+    ptrs = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+    oa = (ctypes.c_int64 * n)(*outers)
+    ia = (ctypes.c_int64 * n)(*inners)
+    if not lib.bvq_absmax_list_supported(dt, n, ptrs, oa, channels, ia):
+        return None
+    with _DeviceGuard(dev):
+        st = stream_ptr(dev)
+        arrive = arrival_buffer(dev, st, max(2 * channels, 18))
+        if arrive is None:
+            return None
+        stat = torch.empty(channels, dtype=xs[0].dtype, device=dev)
+        scale = torch.empty(channels, dtype=scale_dtype, device=dev)
+        check(lib.bvq_absmax_scale_list(dt, n, ptrs, oa, channels, ia, ptr(stat), float(min_val or 0.0),
+                                        int(bool(min_val)), float(int_threshold), dtype_code(scale_dtype), ptr(scale),
+                                        ptr(arrive), arrive.numel(), st), 'bvq_absmax_scale_list')
+    return stat, scale
 
 
 def absmax_scale(x, outer, channels, inner, min_val, int_threshold, scale_dtype, pre_op=PRE_NONE, running=None,

@@ -529,6 +529,117 @@ class StatsGraphFakeQuantFn(Function):
         return (_restore(dx, ctx.back),) + none[1:] + tuple(grads[1:])
 
 
+def _list_views(params, sp):
+    """(flat tensors, outers, inners) of a shared quantizer's parameters as the list kernel takes them"""
+    flats = [t.detach().reshape(-1) for t in params]
+    return flats, [1] * len(params), [t.numel() // sp.channels for t in params]
+
+
+def list_stats_supported(params, sp) -> bool:
+    """the one-launch statistic over a parameter list applies (nat.absmax_scale_list would not return None)"""
+    import ctypes
+    if not config.FUSED_PATHS or params[0].dtype not in _FLOATS or sp.outer != 1 or sp.nhwc:
+        return False
+    flats, outers, inners = _list_views(params, sp)
+    n = len(flats)
+    st = nat.stream_ptr(flats[0].device)
+    if nat.arrival_buffer(flats[0].device, st, max(2 * sp.channels, 18)) is None:
+        return False
+    return bool(nat.lib.bvq_absmax_list_supported(
+        nat.dtype_code(flats[0].dtype), n, (ctypes.c_void_p * n)(*[f.data_ptr() for f in flats]),
+        (ctypes.c_int64 * n)(*outers), sp.channels, (ctypes.c_int64 * n)(*inners)))
+
+
+class ListStatsFakeQuantFn(Function):
+    """StatsFakeQuantFn for a weight quantizer SHARED by several layers: the statistic is AbsMax over the concatenation
+    of all tracked parameters' views (B/core/stats/stats_wrapper.py:83-114, _ParameterListStats with more than one
+    parameter; B/core/scaling/standalone.py StatsFromParameterScaling), the tensor quantized is one of them.
+
+    Forward, two launches: the statistic of the whole list + scale (nat.absmax_scale_list: the concatenation is never
+    built), the quantizer kernel on x.  Backward: the quantizer's backward on x (dx, the scale-gradient sums and x's own
+    arg-max positions on the same reads); the other parameters are scanned for the positions attaining the statistic,
+    and the statistic's gradient goes where torch's backward of max over the concatenation puts it -- per channel on
+    the FIRST position in concatenation order (extra parameters are concatenated in front: the highest list index
+    that attains it), for a whole-tensor statistic evenly over all ties of all parameters -- into dx for x, into zero
+    tensors for the others.  The reference reads
+    and writes every parameter for torch.cat, reduces the copy, and in backward writes a dense gradient of the
+    concatenation and slices it."""
+
+    @staticmethod
+    def forward(ctx, x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, index, *params):
+        ctx.set_materialize_grads(False)
+        flats, outers, inners = _list_views(params, sp)
+        if len(sp.scaling_shape) > 0:
+            scale_dtype, thr_div = x.dtype, _as_dtype_value(sp.int_threshold, x.dtype)
+        else:
+            scale_dtype = torch.promote_types(x.dtype, int_threshold.dtype)
+            thr_div = sp.int_threshold
+        out = nat.absmax_scale_list(flats, outers, sp.channels, inners, sp.min_val, thr_div, scale_dtype)
+        if out is None:
+            raise nat.BvqError('ListStatsFakeQuantFn: list not covered (caller must pre-check list_stats_supported)')
+        stat, scale = out
+        scale = scale.view(sp.scaling_shape)
+        zp = _zero_zero_point(x.device)
+        xc = x.detach()
+        p = Plan(sp.outer, sp.channels, sp.inner, sp.channels > 1, False, torch.result_type(x, scale), False)
+        if not (p.ct == x.dtype or p.ct == torch.float32):
+            raise nat.BvqError('ListStatsFakeQuantFn: unsupported operand layout')
+        sc = scale.reshape(-1).contiguous()
+        desc = make_desc(p, xc, sc, zp.reshape(-1), qmin, qmax, round_mode, clamp_ste, nat.OUT_DEQUANT, nat.PRE_NONE)
+        y = nat.fakequant_fwd(desc, xc, sc, zp.reshape(-1))
+        ctx.desc, ctx.sp, ctx.index, ctx.inners = desc, sp, index, inners
+        ctx.save_for_backward(scale, zp, stat, int_threshold, *params)
+        stat_out = stat.view(sp.scaling_shape)
+        ctx.mark_non_differentiable(stat_out)
+        return y, scale, stat_out
+
+    @staticmethod
+    def backward(ctx, gy, gscale, _gstat):
+        scale, zp, stat, int_threshold = ctx.saved_tensors[:4]
+        params = ctx.saved_tensors[4:]
+        desc, sp, index = ctx.desc, ctx.sp, ctx.index
+        none = (None,) * 8
+        if gy is None and gscale is None:
+            return none + (None,) * len(params)
+        x = params[index].detach()
+        ct = {nat.F32: torch.float32, nat.BF16: torch.bfloat16, nat.F16: torch.float16}[desc.ct_dtype]
+        gy = torch.zeros(x.shape, dtype=ct, device=x.device) if gy is None else gy.to(ct).contiguous()
+        stat_x = stat.reshape(-1).to(x.dtype).contiguous()
+        dx, ds, _, own = nat.fakequant_bwd(desc, gy, x, scale.reshape(-1).contiguous(), zp.reshape(-1), True, False,
+                                           tie_stat=stat_x)
+        ds = _reduce_like(ds, scale)
+        if gscale is not None:
+            ds = ds + gscale
+        # scale = thr / int_threshold  ->  dthr = dscale / int_threshold ; clamp_min_ste passes it on
+        dstat = (ds / int_threshold).to(stat.dtype).reshape(-1).contiguous()
+        ch = sp.channels
+        # the other parameters: one read each, which also writes the zeros their non-attaining elements receive
+        # (0 * sgn(x): the reference's gradient of |x| there, signed zeros included)
+        outs = [dx if i == index else torch.empty_like(t, memory_format=torch.contiguous_format)
+                for i, t in enumerate(params)]
+        infos = [own if i == index else
+                 nat.stat_tie_scan(nat.MATCH_ABS, t.detach().reshape(-1), stat_x, 1, ch, ctx.inners[i],
+                                   dx_zero_fill=outs[i].reshape(-1))
+                 for i, t in enumerate(params)]
+        total = None
+        if ch > 1:
+            # the deposit of channel c belongs to the first tensor IN CONCATENATION ORDER that attains the statistic
+            # there; every extra parameter is concatenated in FRONT of what came before
+            # (B/core/stats/view_wrapper.py:49-50), so that order is the list's, reversed
+            order = list(range(len(infos)))[::-1]
+            first = torch.stack([infos[i][:ch] for i in order])                # [n, channels], -1: not attained
+            has = first >= 0
+            owner = torch.where(has.any(0), has.to(torch.int8).argmax(0), torch.full_like(first[0], -1))
+            for r, i in enumerate(order):
+                infos[i][:ch] = torch.where(owner == r, infos[i][:ch], torch.full_like(infos[i][:ch], -1))
+        else:
+            total = torch.stack([w[0] for w in infos]).sum().reshape(1)        # ties of the whole list share evenly
+        for i, t in enumerate(params):
+            nat.stat_tie_apply(nat.MATCH_ABS, t.detach().reshape(-1), stat_x, dstat, infos[i], outs[i].reshape(-1), 1, ch,
+                               ctx.inners[i], mode_add=(i == index), total_ties=total)
+        return (dx,) + none[1:] + tuple(g if i != index else None for i, g in enumerate(outs))
+
+
 def stats_backward(xc, scale, zp, stat, int_threshold, desc, sp, group, pre_op, back, gy, gscale):
     """backward of StatsFakeQuantFn (also the fallback of the C++ node, brevitas_amd/csrc/bvq_autograd.cpp) -> dx or None;
     sp: anything with outer / channels / inner / int_threshold"""

@@ -81,7 +81,7 @@ class RescalingIntQuant(torch.nn.Module):
         if type(self.zero_point_impl) is not ZeroZeroPoint or type(self.int_scaling_impl) is not IntScaling:
             return None
         sc = self.scaling_impl
-        runtime, weight = None, None
+        runtime, weight, shared = None, None, None
         if type(sc) is RuntimeStatsScaling:
             if not sc.training:
                 return None
@@ -89,10 +89,14 @@ class RescalingIntQuant(torch.nn.Module):
             view, stats = runtime.stats_input_view_shape_impl, runtime.stats
         elif type(sc) is StatsFromParameterScaling:
             pls = sc.parameter_list_stats
-            if pls.extra_tracked_params_list is not None:
-                return None
             weight = pls.first_tracked_param.parameter
             view, stats = pls.first_tracked_param.view_shape_impl, pls.stats
+            if pls.extra_tracked_params_list is not None:
+                # a quantizer shared by several layers: the statistic of all their weights in ONE launch over the list
+                # (_fused.ListStatsFakeQuantFn), no torch.cat
+                if any(type(e.view_shape_impl) is not type(view) for e in pls.extra_tracked_params_list):
+                    return None
+                shared = [weight] + [e.parameter for e in pls.extra_tracked_params_list]
         else:
             return None
         min_val = sc.stats_scaling_impl.bvq_plain_min_val()
@@ -112,7 +116,9 @@ class RescalingIntQuant(torch.nn.Module):
         else:
             return None
         qmin, qmax = int_range_host(iq.signed, iq.narrow_range, bw)
-        return dict(runtime=runtime, weight=weight, view=view, shape=shape, min_val=min_val, post=post,
+        if shared is not None and (post is not None or len(shared) > 8):
+            return None
+        return dict(runtime=runtime, weight=weight, shared=shared, view=view, shape=shape, min_val=min_val, post=post,
                     per_channel=per_channel, int_thr=self.int_scaling_impl.host_value(bw), qmin=qmin, qmax=qmax,
                     round_mode=iq.float_to_int_impl.bvq_round_mode, clamp_ste=iq.tensor_clamp_impl.bvq_clamp_ste)
 
@@ -124,8 +130,20 @@ class RescalingIntQuant(torch.nn.Module):
         if tmpl is None:
             return None
         w = tmpl['weight']
-        if w is not None and not (w is x or (w.data_ptr() == x.data_ptr() and w.shape == x.shape
-                                             and w.stride() == x.stride() and w.dtype == x.dtype)):
+        if tmpl['shared'] is not None:
+            # the tensor being quantized is one of the list; every tensor lies [channels, ...] (or flat) in memory
+            same = [i for i, t in enumerate(tmpl['shared'])
+                    if t is x or (t.data_ptr() == x.data_ptr() and t.shape == x.shape and t.stride() == x.stride())]
+            ch0 = x.shape[0] if tmpl['per_channel'] else None
+            if not same or not x.is_contiguous() or any(
+                    (not t.is_cuda) or t.device != x.device or t.dtype != x.dtype or not t.is_contiguous()
+                    or t.dim() == 0 or t.numel() == 0 or (ch0 is not None and t.shape[0] != ch0)
+                    for t in tmpl['shared']):
+                return None
+            if tmpl['per_channel'] and tmpl['view'].bvq_channel_dim(x.dim()) != 0:
+                return None
+        elif w is not None and not (w is x or (w.data_ptr() == x.data_ptr() and w.shape == x.shape
+                                               and w.stride() == x.stride() and w.dtype == x.dtype)):
             return None  # the statistic is taken of another tensor than the one being quantized
         shape = tmpl['shape']
         if not tmpl['per_channel']:
@@ -250,6 +268,20 @@ class RescalingIntQuant(torch.nn.Module):
             if runtime is not None:
                 runtime.bvq_running_folded = False
             fast = None
+            if tmpl['shared'] is not None:
+                params = tuple(tmpl['shared'])
+                index = next(i for i, t in enumerate(params) if t.data_ptr() == x.data_ptr() and t.shape == x.shape)
+                if pre_op == nat.PRE_NONE and _fused.list_stats_supported(params, sp):
+                    y, scale, stat = _fused.ListStatsFakeQuantFn.apply(
+                        x, int_threshold, sp, tmpl['qmin'], tmpl['qmax'], tmpl['round_mode'], tmpl['clamp_ste'], index,
+                        *params)
+                    zero_point = self.zero_point_impl(x, scale, bit_width)
+                    return y, scale, zero_point, bit_width
+                fused = None  # list not covered by the list kernel: op by op
+                if pre_op != nat.PRE_NONE:
+                    x, pre_op = torch.relu(x), nat.PRE_NONE
+        if fused is not None:
+            sp, tmpl = fused
             if tmpl['post'] is not None:
                 if group is not None:
                     raise NotImplementedError('batch-sharded quantizer with a non-trivial statistic -> scale map')

@@ -1458,6 +1458,129 @@ extern "C" int bvq_absmax_scale_onepass(int pre_op, int dtype, const void* x, in
   return check_launch("bvq_absmax_scale_onepass");
 }
 
+// ---- abs-max of a LIST of tensors sharing the channel axis --------------------------------------------------------
+// _ParameterListStats with several tracked parameters (B/core/stats/stats_wrapper.py:83-114: a weight quantizer shared by
+// several layers takes its statistic of the concatenation of their weights' views).  The reference materialises the
+// concatenation (torch.cat: one read and one write of every parameter) and reduces that; here ONE launch walks every
+// tensor where it lies: the dispatch's waves are dealt to the tensors in order (start[]), a wave finds its tensor by
+// its slot, walks its unit like the one-launch abs-max does and arrives at the channel's words -- the last arriver of
+// a channel, whichever tensor its unit came from, finishes statistic and scale.  A max is exact and order-independent:
+// the bits equal those of the reference's reduction over the concatenation.
+constexpr int kMaxListTensors = 8;
+struct ListStatArgs {
+  StatArgs a[kMaxListTensors];
+  int64_t start[kMaxListTensors + 1];  // first dispatch slot of tensor i; start[n] = all slots
+  int32_t vec[kMaxListTensors];        // elements per load of tensor i: 16 bytes' worth, or 1 (short / misaligned rows)
+  int32_t n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void absmax_list_kernel(ListStatArgs la, ArriveArgs r, ScaleEpilogue ep) {
+  constexpr int V = elem<T>::vec;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int64_t slot = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (slot >= la.start[la.n]) return;
+  int p = 0;
+  while (p + 1 < la.n && slot >= la.start[p + 1]) ++p;  // (wave-uniform)
+  const Unit u = locate_unit_slot(la.a[p].t, slot - la.start[p]);  // valid: start[] holds the tilings' own unit counts
+  const uint32_t m = la.vec[p] == V ? onepass_unit_max<T, V, false, false>(la.a[p], u, lane)
+                                    : onepass_unit_max<T, 1, false, false>(la.a[p], u, lane);  // (wave-uniform)
+  absmax_arrive(r, ep, u.channel, m, 1u, lane);
+}
+
+// tilings of the list's tensors, units per channel over the whole list
+static bool list_tilings(int dtype, int n, const void* const* xs, const int64_t* outers, int64_t channels,
+                         const int64_t* inners, ListStatArgs& la, int64_t& per_channel) {
+  if (n < 1 || n > kMaxListTensors || channels < 1) return false;
+  per_channel = 0;
+  la.n = n;
+  la.start[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    if (outers[i] < 1 || inners[i] < 1 || !xs[i]) return false;
+    int v;
+    Tiling& t = la.a[i].t;
+    if (!onepass_tiling(dtype, xs[i], outers[i], channels, inners[i], t, v)) return false;
+    if (channels == 1) {
+      // a whole-tensor statistic: few, long pieces -- every unit of every tensor arrives at ONE pair of words
+      const int64_t cap = kMaxArrivalsPerChannel / n;
+      if (t.nob * t.ppr > cap && t.nob == 1) {
+        const int64_t quantum = (int64_t)kWave * v;
+        int64_t piece = (t.row_len + cap - 1) / cap;
+        piece = ((piece + quantum - 1) / quantum) * quantum;
+        t.piece_len = piece;
+        t.ppr = (t.row_len + piece - 1) / piece;
+        t.units = t.nob * t.ppr;
+        if (!cap_unit_extent(t, dtype_size(dtype))) return false;
+      }
+    }
+    la.vec[i] = v;
+    la.a[i].x = xs[i];
+    la.start[i + 1] = la.start[i] + t.units;
+    per_channel += t.nob * t.ppr;
+  }
+  return per_channel <= kMaxArrivalsPerChannel && la.start[n] < ((int64_t)1 << 31);
+}
+
+extern "C" int bvq_absmax_list_supported(int dtype, int n, const void* const* xs, const int64_t* outers,
+                                         int64_t channels, const int64_t* inners) {
+  if (bad_dtype(dtype) || !xs || !outers || !inners) return 0;
+  ListStatArgs la = {};
+  int64_t per_channel;
+  return list_tilings(dtype, n, xs, outers, channels, inners, la, per_channel) ? 1 : 0;
+}
+
+extern "C" int bvq_absmax_scale_list(int dtype, int n, const void* const* xs, const int64_t* outers, int64_t channels,
+                                     const int64_t* inners, void* stat_out, double min_val, int use_min,
+                                     double int_threshold, int scale_dtype, void* scale_out, uint32_t* arrive,
+                                     int64_t arrive_words, bvq_stream_t stream) {
+  if (bad_dtype(dtype) || (scale_out && bad_dtype(scale_dtype)) || (scale_out && !(int_threshold == int_threshold))) {
+    set_error("bvq_absmax_scale_list: bad argument");
+    return BVQ_ERR_INVALID;
+  }
+  if (!xs || !outers || !inners || !stat_out || !arrive) {
+    set_error("bvq_absmax_scale_list: null pointer");
+    return BVQ_ERR_INVALID;
+  }
+  ListStatArgs la = {};
+  int64_t per_channel;
+  if (!list_tilings(dtype, n, xs, outers, channels, inners, la, per_channel)) {
+    set_error("bvq_absmax_scale_list: list not covered (1..%d tensors, <= %lld units per channel)",
+              kMaxListTensors, (long long)kMaxArrivalsPerChannel);
+    return BVQ_ERR_UNSUPPORTED;
+  }
+  if (arrive_words < onepass_arrive_words(channels)) {
+    set_error("bvq_absmax_scale_list: arrival buffer of %lld words, %lld needed", (long long)arrive_words,
+              (long long)onepass_arrive_words(channels));
+    return BVQ_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  ArriveArgs r;
+  r.key = arrive;
+  r.cnt = arrive + channels;
+  r.per_channel = (uint32_t)per_channel;
+  r.stat_out = stat_out;
+  r.stat_dtype = dtype;
+  r.in_dtype = dtype;
+  r.part = nullptr;
+  ScaleEpilogue ep = {};
+  if (scale_out) {
+    ep.scale_out = scale_out;
+    ep.scale_dtype = scale_dtype;
+    ep.use_min = use_min;
+    ep.min_val = round_host((float)min_val, dtype);  // python scalar -> the statistic's dtype
+    ep.int_threshold = (float)int_threshold;
+  }
+  const dim3 grid(grid_for_units(la.start[n])), block(kBlock);
+  if (dtype == BVQ_F32)
+    absmax_list_kernel<float><<<grid, block, 0, st>>>(la, r, ep);
+  else if (dtype == BVQ_BF16)
+    absmax_list_kernel<bf16_t><<<grid, block, 0, st>>>(la, r, ep);
+  else
+    absmax_list_kernel<f16_t><<<grid, block, 0, st>>>(la, r, ep);
+  return check_launch("bvq_absmax_scale_list");
+}
+
 extern "C" int bvq_absmax_scale_running(int pre_op, int dtype, const void* x, int64_t outer, int64_t channels,
                                         int64_t inner, void* stat_out, double min_val, int use_min,
                                         double int_threshold, int scale_dtype, void* scale_out, int run_dtype,

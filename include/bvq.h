@@ -219,6 +219,23 @@ int bvq_absmax_scale_onepass(int pre_op, int dtype, const void* x, int64_t outer
                              int scale_dtype, void* scale_out, int run_dtype, void* running, double momentum,
                              int first_batch, uint32_t* arrive, int64_t arrive_words, bvq_stream_t stream);
 
+/* AbsMax of a LIST of tensors that share the channel axis, + the scale epilogue, in ONE launch: the statistic of
+ * _ParameterListStats with several tracked parameters (B/core/stats/stats_wrapper.py:83-114 -- a weight quantizer shared
+ * by several layers reduces torch.cat of their weights' views; B/core/scaling/standalone.py StatsFromParameterScaling).
+ * Tensor i is contiguous [outers[i], channels, inners[i]] of `dtype` (per output channel: outers = 1, inners = the
+ * row of channel c; whole tensor: channels = 1, inners = numel).  No concatenation is materialised: the launch's waves
+ * are dealt to the tensors, and the last wave to arrive at a channel's words finishes that channel (contract of the
+ * arrival buffer: bvq_absmax_scale_onepass).  stat_out [channels] in `dtype`; scale_out nullable.  The bits are those
+ * of the reference's reduction over the concatenation (a max is exact).
+ * bvq_absmax_list_supported: 1 / 0 -- 1..8 tensors, at most 512 units per channel over the whole list.
+ * BVQ_ERR_UNSUPPORTED otherwise: reduce the tensors one by one. */
+int bvq_absmax_list_supported(int dtype, int n, const void* const* xs, const int64_t* outers, int64_t channels,
+                              const int64_t* inners);
+int bvq_absmax_scale_list(int dtype, int n, const void* const* xs, const int64_t* outers, int64_t channels,
+                          const int64_t* inners, void* stat_out, double min_val, int use_min, double int_threshold,
+                          int scale_dtype, void* scale_out, uint32_t* arrive, int64_t arrive_words,
+                          bvq_stream_t stream);
+
 /* Running average kept by _RuntimeStats (B/core/stats/stats_wrapper.py:61-66), one launch:
  *   first_batch: running *= stat ; otherwise running *= (1 - momentum); running += momentum * stat
  * with torch's rounding points (in-place results in run_dtype, momentum * stat in stat_dtype). */

@@ -936,10 +936,63 @@ def gen_channel_last():
     st.save()
 
 
+# ------------------------------------------------------------------------------------------------
+# N. a weight quantizer SHARED by several layers: _ParameterListStats over more than one tracked parameter
+#    (B/core/stats/stats_wrapper.py:83-114) -- the statistic is AbsMax of the concatenation of the weights' views, the
+#    tensor quantized is each of them in turn; gradients reach every parameter through the concatenation
+# ------------------------------------------------------------------------------------------------
+def gen_shared():
+    st = Store('shared')
+    for dn in ('f32', 'bf16', 'f16'):
+        for tag in ('per_channel', 'per_tensor'):
+            for shapes in (((8, 6, 3, 3), (8, 4, 1, 1)), ((8, 16), (8, 40), (8, 8))):
+                ws = []
+                for k, shape in enumerate(shapes):
+                    w = torch.randn(shape) * 0.05 * (1 + k)
+                    ws.append(w)
+                # ties: channel 1's maximum appears in the first AND the second tensor (the second is concatenated in front and
+                # owns it), channel 2's
+                # twice inside the last tensor, channel 3 is all zero everywhere; per tensor: the global maximum twice
+                ws[0].view(8, -1)[1, 2] = 0.75
+                ws[1].view(8, -1)[1, 1] = -0.75
+                ws[-1].view(8, -1)[2, 0] = 0.875
+                ws[-1].view(8, -1)[2, 3] = 0.875
+                for w in ws:
+                    w.view(8, -1)[3] = 0.0
+                if tag == 'per_tensor':
+                    ws[0].view(-1)[5] = 1.5
+                    ws[-1].view(-1)[7] = -1.5
+                ws = [torch.nn.Parameter(w.to(DT[dn])) for w in ws]
+                if tag == 'per_channel':
+                    scaling = StatsFromParameterScaling(AbsMax(1), OverOutputChannelView(None), 1, ws, FloatRestrictValue(),
+                                                        (8,) + (1,) * (ws[0].dim() - 1), affine_rescaling=False,
+                                                        scaling_min_val=1e-10)
+                else:
+                    scaling = StatsFromParameterScaling(AbsMax(), OverTensorView(), 0, ws, FloatRestrictValue(), (),
+                                                        affine_rescaling=False, scaling_min_val=1e-10)
+                q = RescalingIntQuant(
+                    IntQuant(narrow_range=True, signed=True, float_to_int_impl=RoundSte(),
+                             tensor_clamp_impl=TensorClampSte()),
+                    scaling, IntScaling(signed=True, narrow_range=True), ZeroZeroPoint(), BitWidthConst(8))
+                for index in range(len(ws)):
+                    for w in ws:
+                        w.grad = None
+                    y, scale, zp, bwt = q(ws[index])
+                    g = torch.randn(y.shape).to(y.dtype)
+                    y.backward(g)
+                    arrays = dict(g=g, y=y, scale=scale)
+                    for k, w in enumerate(ws):
+                        arrays['w%d' % k] = w.data
+                        arrays['dw%d' % k] = w.grad if w.grad is not None else torch.zeros_like(w)
+                    st.case({'graph': 'shared_weight', 'tag': tag, 'dtype': dn, 'index': index, 'n': len(ws),
+                             'shapes': [list(sh) for sh in shapes]}, **arrays)
+    st.save()
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     only = sys.argv[1:]
-    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point', 'learned_bw', 'moments', 'kl', 'affine', 'channel_last'}:
+    if not only or not set(only) <= {'act_fused', 'percentile', 'shifted', 'variants', 'fixed_point', 'learned_bw', 'moments', 'kl', 'affine', 'channel_last', 'shared'}:
         # the first four files were generated in ONE run, in this order, from a single seed
         torch.manual_seed(123456)
         gen_ste()
@@ -976,3 +1029,6 @@ if __name__ == '__main__':
     if not only or 'channel_last' in only:
         torch.manual_seed(123466)
         gen_channel_last()
+    if not only or 'shared' in only:
+        torch.manual_seed(123467)
+        gen_shared()
