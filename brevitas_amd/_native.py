@@ -107,7 +107,7 @@ def _load(path=None, strict=True):
         'bvq_absmax_onepass_supported': (i32, [i32, vp, i64, i64, i64]),
         'bvq_absmax_scale_onepass': (i32, [i32, i32, vp, i64, i64, i64, i32, vp, dbl, i32, dbl, i32, vp, i32, vp, dbl, i32, vp, i64, vp]),
         'bvq_absmax_list_supported': (i32, [i32, i32, vp, vp, i64, vp]),
-        'bvq_absmax_scale_list': (i32, [i32, i32, vp, vp, i64, vp, vp, dbl, i32, dbl, i32, vp, vp, i64, vp]),
+        'bvq_absmax_scale_list': (i32, [i32, i32, vp, vp, i64, vp, vp, dbl, i32, dbl, i32, vp, vp, i64, vp, i64, vp]),
         'bvq_running_stats_update': (i32, [i32, vp, i32, vp, i64, dbl, i32, vp]),
         'bvq_scale_from_stat': (i32, [vp, i64, i32, vp, dbl, i32, dbl, i32, vp, vp]),
         'bvq_scale_from_stat_running': (i32, [vp, i64, i32, vp, dbl, i32, dbl, i32, vp, i32, vp, dbl, i32, vp]),
@@ -441,14 +441,19 @@ def absmax_scale_list(xs, outers, channels, inners, min_val, int_threshold, scal
         return None
     with _DeviceGuard(dev):
         st = stream_ptr(dev)
-        arrive = arrival_buffer(dev, st, max(2 * channels, 18))
-        if arrive is None:
-            return None
+        arrive = ws = None
+        if channels > 1:
+            arrive = arrival_buffer(dev, st, max(2 * channels, 18))
+            if arrive is None:
+                return None
+        else:  # a whole-tensor statistic: one partial per unit (<= 4096) and a finishing launch
+            ws = torch.empty(1 << 14, dtype=torch.uint8, device=dev)
         stat = torch.empty(channels, dtype=xs[0].dtype, device=dev)
         scale = torch.empty(channels, dtype=scale_dtype, device=dev)
         check(lib.bvq_absmax_scale_list(dt, n, ptrs, oa, channels, ia, ptr(stat), float(min_val or 0.0),
                                         int(bool(min_val)), float(int_threshold), dtype_code(scale_dtype), ptr(scale),
-                                        ptr(arrive), arrive.numel(), st), 'bvq_absmax_scale_list')
+                                        ptr(arrive), arrive.numel() if arrive is not None else 0, ptr(ws),
+                                        ws.numel() if ws is not None else 0, st), 'bvq_absmax_scale_list')
     return stat, scale
 
 

@@ -543,7 +543,7 @@ def list_stats_supported(params, sp) -> bool:
     flats, outers, inners = _list_views(params, sp)
     n = len(flats)
     st = nat.stream_ptr(flats[0].device)
-    if nat.arrival_buffer(flats[0].device, st, max(2 * sp.channels, 18)) is None:
+    if sp.channels > 1 and nat.arrival_buffer(flats[0].device, st, max(2 * sp.channels, 18)) is None:
         return False
     return bool(nat.lib.bvq_absmax_list_supported(
         nat.dtype_code(flats[0].dtype), n, (ctypes.c_void_p * n)(*[f.data_ptr() for f in flats]),

@@ -1355,8 +1355,11 @@ static bool onepass_layout(int dtype, const void* x, int64_t outer, int64_t chan
   if ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && cols_plan(dtype, outer, channels, inner).ok) return false;
   return true;
 }
-// arrivals at one channel's words: beyond this the atomics on one address serialise into microseconds
-constexpr int64_t kMaxArrivalsPerChannel = 512;
+// arrivals at one channel's words: agent-scope atomics on ONE address serialise at ~0.25 us each across the XCDs --
+// [1024,16,32,32] with 512 arrivals per channel ran 126 us against the two-launch route's 18, [256,64,56,56] (128) 57
+// against 25, [256,128,56,56] (64) 41 against 39, [64,256,56,56] (32) level, 16 and fewer ahead
+// (profiles/r03_onepass.txt, section 6)
+constexpr int64_t kMaxArrivalsPerChannel = 32;
 static inline int64_t onepass_arrive_words(int64_t channels) { return 2 * channels; }
 
 extern "C" int bvq_absmax_onepass_supported(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner) {
@@ -1486,6 +1489,11 @@ __global__ __launch_bounds__(kBlock) void absmax_list_kernel(ListStatArgs la, Ar
   const Unit u = locate_unit_slot(la.a[p].t, slot - la.start[p]);  // valid: start[] holds the tilings' own unit counts
   const uint32_t m = la.vec[p] == V ? onepass_unit_max<T, V, false, false>(la.a[p], u, lane)
                                     : onepass_unit_max<T, 1, false, false>(la.a[p], u, lane);  // (wave-uniform)
+  if (r.part) {  // (wave-uniform) whole-tensor statistic: one partial per unit, a finishing launch follows
+    const uint32_t mw = wave_max_u32(m);
+    if (lane == 0) r.part[slot] = mw;
+    return;
+  }
   absmax_arrive(r, ep, u.channel, m, 1u, lane);
 }
 
@@ -1502,8 +1510,9 @@ static bool list_tilings(int dtype, int n, const void* const* xs, const int64_t*
     Tiling& t = la.a[i].t;
     if (!onepass_tiling(dtype, xs[i], outers[i], channels, inners[i], t, v)) return false;
     if (channels == 1) {
-      // a whole-tensor statistic: few, long pieces -- every unit of every tensor arrives at ONE pair of words
-      const int64_t cap = kMaxArrivalsPerChannel / n;
+      // a whole-tensor statistic: few, long pieces -- the units leave one partial each and ONE finishing launch
+      // (a workgroup over <= kFinishSlice partials) follows; arrivals at a single pair of words would serialise
+      const int64_t cap = kFinishSlice / n;
       if (t.nob * t.ppr > cap && t.nob == 1) {
         const int64_t quantum = (int64_t)kWave * v;
         int64_t piece = (t.row_len + cap - 1) / cap;
@@ -1519,6 +1528,7 @@ static bool list_tilings(int dtype, int n, const void* const* xs, const int64_t*
     la.start[i + 1] = la.start[i] + t.units;
     per_channel += t.nob * t.ppr;
   }
+  if (channels == 1) return la.start[n] <= kFinishSlice;
   return per_channel <= kMaxArrivalsPerChannel && la.start[n] < ((int64_t)1 << 31);
 }
 
@@ -1533,25 +1543,31 @@ extern "C" int bvq_absmax_list_supported(int dtype, int n, const void* const* xs
 extern "C" int bvq_absmax_scale_list(int dtype, int n, const void* const* xs, const int64_t* outers, int64_t channels,
                                      const int64_t* inners, void* stat_out, double min_val, int use_min,
                                      double int_threshold, int scale_dtype, void* scale_out, uint32_t* arrive,
-                                     int64_t arrive_words, bvq_stream_t stream) {
+                                     int64_t arrive_words, void* workspace, int64_t workspace_bytes,
+                                     bvq_stream_t stream) {
   if (bad_dtype(dtype) || (scale_out && bad_dtype(scale_dtype)) || (scale_out && !(int_threshold == int_threshold))) {
     set_error("bvq_absmax_scale_list: bad argument");
     return BVQ_ERR_INVALID;
   }
-  if (!xs || !outers || !inners || !stat_out || !arrive) {
+  if (!xs || !outers || !inners || !stat_out || (channels > 1 && !arrive)) {
     set_error("bvq_absmax_scale_list: null pointer");
     return BVQ_ERR_INVALID;
   }
   ListStatArgs la = {};
   int64_t per_channel;
   if (!list_tilings(dtype, n, xs, outers, channels, inners, la, per_channel)) {
-    set_error("bvq_absmax_scale_list: list not covered (1..%d tensors, <= %lld units per channel)",
+    set_error("bvq_absmax_scale_list: list not covered (1..%d tensors, <= %lld units per channel, one row per tensor)",
               kMaxListTensors, (long long)kMaxArrivalsPerChannel);
     return BVQ_ERR_UNSUPPORTED;
   }
-  if (arrive_words < onepass_arrive_words(channels)) {
+  if (channels > 1 && arrive_words < onepass_arrive_words(channels)) {
     set_error("bvq_absmax_scale_list: arrival buffer of %lld words, %lld needed", (long long)arrive_words,
               (long long)onepass_arrive_words(channels));
+    return BVQ_ERR_WORKSPACE;
+  }
+  if (channels == 1 && (!workspace || workspace_bytes < la.start[n] * (int64_t)sizeof(uint32_t))) {
+    set_error("bvq_absmax_scale_list: workspace %lld < %lld bytes", (long long)workspace_bytes,
+              (long long)(la.start[n] * (int64_t)sizeof(uint32_t)));
     return BVQ_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -1562,7 +1578,7 @@ extern "C" int bvq_absmax_scale_list(int dtype, int n, const void* const* xs, co
   r.stat_out = stat_out;
   r.stat_dtype = dtype;
   r.in_dtype = dtype;
-  r.part = nullptr;
+  r.part = channels == 1 ? reinterpret_cast<uint32_t*>(workspace) : nullptr;
   ScaleEpilogue ep = {};
   if (scale_out) {
     ep.scale_out = scale_out;
@@ -1578,6 +1594,12 @@ extern "C" int bvq_absmax_scale_list(int dtype, int n, const void* const* xs, co
     absmax_list_kernel<bf16_t><<<grid, block, 0, st>>>(la, r, ep);
   else
     absmax_list_kernel<f16_t><<<grid, block, 0, st>>>(la, r, ep);
+  if (channels == 1) {
+    int rc = check_launch("bvq_absmax_scale_list");
+    if (rc) return rc;
+    stat_finish_kernel<BVQ_STAT_ABSMAX><<<dim3(1), dim3(kBlock), 0, st>>>(r.part, r.part, stat_out, dtype, dtype, 1, 1,
+                                                                          la.start[n], ep, nullptr, nullptr);
+  }
   return check_launch("bvq_absmax_scale_list");
 }
 

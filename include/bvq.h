@@ -207,8 +207,9 @@ int bvq_absmax_scale_running(int pre_op, int dtype, const void* x, int64_t outer
  * B/core/restrict_val.py:22-42 and B/core/quant/int.py:160 -> scale_out; B/core/stats/stats_wrapper.py:61-66 ->
  * running).  No wave waits for another.  Results are the bits of bvq_absmax_scale[_running] (a max is exact).
  * stat_dtype: BVQ_F32 (the batch-sharded route all-reduces it) or the dtype of x.  scale_out / running: nullable.
- * Not covered (bvq_absmax_onepass_supported: 0): a whole-tensor statistic and per-channel layouts with more than 512
- * units per channel -- hundreds of arrivals at one word cost more than the finishing launch they would save.
+ * Not covered (bvq_absmax_onepass_supported: 0): a whole-tensor statistic and per-channel layouts with more than 32
+ * units per channel -- arrivals at one word serialise (~0.25 us each) and soon cost more than the finishing launch
+ * they would save.
  * arrive: `arrive_words` >= 2 * channels uint32 words in device memory that are ALL ZERO when the launch starts;
  *   the finishing waves hand them back as zeros, so a caller keeps ONE such buffer per stream, cleared once when
  *   it is allocated, and never clears it again (launches on one stream are ordered; do not share it between streams).
@@ -227,14 +228,17 @@ int bvq_absmax_scale_onepass(int pre_op, int dtype, const void* x, int64_t outer
  * are dealt to the tensors, and the last wave to arrive at a channel's words finishes that channel (contract of the
  * arrival buffer: bvq_absmax_scale_onepass).  stat_out [channels] in `dtype`; scale_out nullable.  The bits are those
  * of the reference's reduction over the concatenation (a max is exact).
- * bvq_absmax_list_supported: 1 / 0 -- 1..8 tensors, at most 512 units per channel over the whole list.
+ * A whole-tensor statistic (channels = 1) leaves one partial per unit in `workspace` (>= 16 KiB) and takes a second,
+ * finishing launch instead of the arrivals: every unit of every tensor would arrive at ONE pair of words, and
+ * agent-scope atomics on one address serialise.  `arrive` may be null then; `workspace` may be null for channels > 1.
+ * bvq_absmax_list_supported: 1 / 0 -- 1..8 tensors, at most 32 units per channel over the whole list.
  * BVQ_ERR_UNSUPPORTED otherwise: reduce the tensors one by one. */
 int bvq_absmax_list_supported(int dtype, int n, const void* const* xs, const int64_t* outers, int64_t channels,
                               const int64_t* inners);
 int bvq_absmax_scale_list(int dtype, int n, const void* const* xs, const int64_t* outers, int64_t channels,
                           const int64_t* inners, void* stat_out, double min_val, int use_min, double int_threshold,
                           int scale_dtype, void* scale_out, uint32_t* arrive, int64_t arrive_words,
-                          bvq_stream_t stream);
+                          void* workspace, int64_t workspace_bytes, bvq_stream_t stream);
 
 /* Running average kept by _RuntimeStats (B/core/stats/stats_wrapper.py:61-66), one launch:
  *   first_batch: running *= stat ; otherwise running *= (1 - momentum); running += momentum * stat
