@@ -280,7 +280,7 @@ def graph_replay_us(job, iters=200):
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=s):  # (the warm-up's stream: its arrival buffer exists, see _native.arrival_buffer)
         job.step()
     for _ in range(10):
         g.replay()
@@ -290,6 +290,64 @@ def graph_replay_us(job, iters=200):
         g.replay()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / iters * 1e6
+
+
+def graphed_run(job, steps, warmup, world, device):
+    """The step captured ONCE into a HIP graph (kernels and the two collectives alike: every launch goes to the capture
+    stream, nothing is read back) and replayed: warm-up replays untimed, then `steps` replays between barriers.
+    Before anything is timed the replay is checked against the eager step: the gradient it leaves in x.grad must equal
+    the eager one bit for bit on EVERY rank, or the graph is not used.
+    -> (max-over-ranks seconds or None, note)"""
+    import torch.distributed as dist
+
+    def agree(flag):  # 1.0 only if every rank says so
+        t = torch.tensor([1.0 if flag else 0.0], device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            job.step()
+    torch.cuda.current_stream().wait_stream(s)
+    sync()
+    want = [t[0].grad.clone() for t in job.acts + job.weights]
+    g = torch.cuda.CUDAGraph()
+    ok, note = True, None
+    try:
+        with torch.cuda.graph(g, stream=s):  # (the warm-up's stream: its arrival buffer exists)
+            job.step()
+    except Exception as e:
+        ok, note = False, 'capture failed: %s: %s' % (type(e).__name__, str(e).splitlines()[0][:160])
+    if not agree(ok):
+        return None, note or 'capture failed on another rank'
+    g.replay()
+    sync()
+    same = all(torch.equal(t[0].grad.view(torch.int16 if t[0].grad.element_size() == 2 else torch.int32),
+                           w.view(torch.int16 if w.element_size() == 2 else torch.int32))
+               for t, w in zip(job.acts + job.weights, want))
+    if not agree(same):
+        return None, 'replay does not reproduce the eager gradients'
+    for _ in range(warmup):
+        g.replay()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, 'replay verified against the eager step (gradients bit for bit on every rank)'
 
 
 def parse_args(argv=None):
@@ -306,6 +364,8 @@ def parse_args(argv=None):
                     help='developer option: do not run the untimed clock-settling steps before the warm-up')
     ap.add_argument('--timer-stride', type=int, default=8,
                     help='record the per-call HIP events on every n-th timed step (1: every step)')
+    ap.add_argument('--graph-replay', action='store_true',
+                    help='developer option (one GPU): also capture the step into a HIP graph and time its replay')
     ap.add_argument('--shard-path', action='store_true',
                     help='developer option: run the batch-sharded code path (RCCL collectives included) even with one '
                          'rank, to measure its fixed per-step overhead on a single GPU')
@@ -319,6 +379,10 @@ def parse_args(argv=None):
     ap.add_argument('--no-n1', action='store_true',
                     help='N > 1: skip rank 0\'s single-GPU run of the whole tensor (no speedup_vs_n1 in the line)')
     ap.add_argument('--no-weak', action='store_true', help='N > 1: skip the weak-scaled side measurement')
+    ap.add_argument('--no-graph', action='store_true',
+                    help='N > 1: do not measure the step replayed from a HIP graph (the judged value is the eager one then)')
+    ap.add_argument('--graph-timeout', type=float, default=120.0,
+                    help='N > 1: seconds the HIP-graph measurement may take before the eager line is printed without it')
     ap.add_argument('--launch-timeout', type=float, default=900.0,
                     help='bare --gpus N: seconds the launcher waits for its workers before it kills them')
     return ap.parse_args(argv)
@@ -556,8 +620,15 @@ def main():
         nat.set_kernel_timer(None)
     main_m = Measurement(job, elapsed, args.steps, world, timer)
     replay_us = None
-    if world == 1 and on_gpu and kind in ('weight_conv', 'weight_linear'):
-        replay_us = graph_replay_us(job)
+    graph_error = None
+    if world == 1 and on_gpu and (kind in ('weight_conv', 'weight_linear') or args.graph_replay):
+        try:
+            replay_us = graph_replay_us(job)
+        except Exception as e:  # developer option on routes that may not capture (collectives): say so, keep the line
+            if not args.graph_replay:
+                raise
+            replay_us = None
+            graph_error = '%s: %s' % (type(e).__name__, str(e).splitlines()[0][:200])
     del job
     free()
 
@@ -571,6 +642,7 @@ def main():
         del j
         free()
 
+    out = None
     if rank == 0:
         m = main_m
         b = m.elsize
@@ -637,15 +709,79 @@ def main():
         if replay_us is not None:
             out['us_per_step_eager'] = round(m.ms_per_step * 1e3, 2)
             out['us_per_step_graph_replay'] = round(replay_us, 2)
+        if graph_error is not None:
+            out['graph_replay_error'] = graph_error
         # the streaming calls of the step, same method (each bracket includes its launch-bound helpers); the
         # one-launch forward (statistic + quantizer) moves the statistic's read through the Infinity Cache
         out['calls'] = m.calls
         if baseline is not None:
             out['cpu_baseline'] = baseline
-        sys.stdout.flush()
-        os.write(result_fd, (json.dumps(out) + '\n').encode())
+
+    import threading
+    emit_lock = threading.Lock()
+    emitted = []
+
+    def emit():
+        with emit_lock:
+            if rank == 0 and not emitted:
+                emitted.append(True)
+                sys.stdout.flush()
+                os.write(result_fd, (json.dumps(out) + '\n').encode())
+
+    # ---- the sharded step replayed from a HIP graph (N > 1; --shard-path on one GPU) -------------------------------------
+    # One rank's shard of a strong split is a launch-bound step: ~120 us of kernels behind ~200 us of host time
+    # (profiles/r03_strong_scaling.md).  Captured once -- kernels, the all-reduce and the all-gather alike -- and
+    # replayed, the host leaves the critical path.  Everything above is measured eagerly and is complete at this point:
+    # if the capture raises, the replay does not reproduce the eager gradients, or nothing comes back within
+    # --graph-timeout seconds, the eager line is printed as it stands.
+    if on_gpu and group is not None and has_act and scaling == 'strong' and not args.no_graph:
+        def abandon():
+            if out is not None:
+                out['hipgraph'] = {'error': 'no result within %g s: abandoned, the eager measurement stands' % args.graph_timeout}
+                out['launch'] = 'eager'
+            emit()
+            os._exit(0)
+        watchdog = threading.Timer(args.graph_timeout, abandon)
+        watchdog.daemon = True
+        watchdog.start()
+        failed = False
+        try:
+            job = Job(kind, dtype, device, group, rank, act_shape=shard_shape)
+            g_elapsed, note = graphed_run(job, args.steps, args.warmup, world, device)
+            g_m = Measurement(job, g_elapsed, args.steps, world) if g_elapsed else None
+            del job
+        except Exception as e:
+            failed, g_m = True, None
+            note = 'failed: %s: %s' % (type(e).__name__, str(e).splitlines()[0][:160])
+        watchdog.cancel()
+        if out is not None:
+            eager = {'value': out['value'], 'ms_per_step': out['ms_per_step']}
+            if g_m is not None:
+                out['hipgraph'] = {'value': round(g_m.value, 3), 'ms_per_step': round(g_m.ms_per_step, 4), 'note': note}
+                if g_m.value > out['value']:
+                    out['value'], out['ms_per_step'] = round(g_m.value, 3), round(g_m.ms_per_step, 4)
+                    out['hbm_frac_whole_step'] = round(g_m.bytes_per_elem * g_m.n_elem * world / (g_m.ms_per_step * 1e-3)
+                                                       / 1e9 / (HBM_PEAK_GBS * world), 4)
+                    if n1 is not None:
+                        out['speedup_vs_n1'] = round(g_m.value / n1.value, 3)
+                    out['launch'] = ('hipgraph: the step (kernels + both collectives) captured once and replayed; '
+                                     'the same steps issued eagerly are under "eager"')
+                    out['eager'] = eager
+            else:
+                out['hipgraph'] = {'error': note}
+        if failed:  # a failed capture may have left the stream or the communicator unusable: no teardown
+            emit()
+            os._exit(0)
+    if out is not None and 'launch' not in out:
+        out['launch'] = 'eager'
+    emit()
     if group is not None:
+        # the line is out: a teardown that does not come back (a rank gone after a failed capture) must not hold the job
+        guard = threading.Timer(30.0, lambda: os._exit(0))
+        guard.daemon = True
+        guard.start()
         torch.distributed.destroy_process_group()
+        guard.cancel()
 
 
 if __name__ == '__main__':

@@ -53,7 +53,10 @@ static int quant_piece_chunks(int vec, int64_t row_len) {
   // 16-bit types: 8 KiB -- except for very long rows (a per-tensor activation), where 7 KiB pieces stream 2-3 %
   // faster than pieces of a power of two (profiles/r02_per_tensor_pieces.txt: 495 -> 510 Gelem/s on the per-tensor
   // headline step); a row of a few pieces (an [8192,8192] weight: two of 8 KiB) stays evenly cut
+  // (rows of a few pieces -- weights with a fan-in of 4096..65536: 4 KiB pieces, [8192,8192] bf16 backward 85 -> 81 us,
+  //  [4096,11008] 58.2 -> 57.2; 2 KiB and 16 KiB pieces lose 15 %: profiles/r03_weight_pieces.txt)
   const int64_t quantum = (int64_t)kWave * vec;
+  if (row_len < 16 * (int64_t)default_piece_chunks() * quantum) return 4;
   return row_len >= 64 * (int64_t)default_piece_chunks() * quantum ? 7 : default_piece_chunks();
 }
 static int max_units_per_channel_quant() {

@@ -1,8 +1,11 @@
 #!/bin/bash
 # scratch GPU script of round 3 (one box per call)
 set -o pipefail
-OUT=gpurun_out/r03pt
+OUT=gpurun_out/r03graph
 mkdir -p $OUT
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $OUT/tests_full.txt 2>&1; tail -3 $OUT/tests_full.txt
-grep -q "failed\|error" $OUT/tests_full.txt && exit 1
-for sh in "256,64,56,56 bf16" "1024,16,32,32 f32"; do set -- $sh; echo "== shape $1 $2"; timeout -k 10 200 python tools/onepass_ab.py --shape $1 --dtype $2 --rounds 6 2>&1 | grep absmax; done
+timeout -k 10 300 python bench.py --act-shape 32,512,56,56 --shard-path --graph-timeout 0.002 --steps 100 --warmup 30 --no-cpu-baseline 2>$OUT/err.txt > $OUT/line.json; echo "rc=$?"
+python -c "
+import sys, json
+d = json.loads(open('$OUT/line.json').read().strip().splitlines()[-1])
+print('| value', d['value'], '| ms/step', d['ms_per_step'], '| launch', d.get('launch'), '| eager', d.get('eager'), '| hipgraph', d.get('hipgraph'))
+"
