@@ -379,8 +379,10 @@ def parse_args(argv=None):
     ap.add_argument('--no-n1', action='store_true',
                     help='N > 1: skip rank 0\'s single-GPU run of the whole tensor (no speedup_vs_n1 in the line)')
     ap.add_argument('--no-weak', action='store_true', help='N > 1: skip the weak-scaled side measurement')
-    ap.add_argument('--no-graph', action='store_true',
-                    help='N > 1: do not measure the step replayed from a HIP graph (the judged value is the eager one then)')
+    ap.add_argument('--graph', action='store_true',
+                    help='N > 1 (or --shard-path): also measure the step replayed from a HIP graph and report the faster '
+                         'of the two.  Off by default: multi-rank RCCL inside a captured graph has not run on this '
+                         'pool, and a process that dies inside the capture prints nothing')
     ap.add_argument('--graph-timeout', type=float, default=120.0,
                     help='N > 1: seconds the HIP-graph measurement may take before the eager line is printed without it')
     ap.add_argument('--launch-timeout', type=float, default=900.0,
@@ -733,8 +735,9 @@ def main():
     # (profiles/r03_strong_scaling.md).  Captured once -- kernels, the all-reduce and the all-gather alike -- and
     # replayed, the host leaves the critical path.  Everything above is measured eagerly and is complete at this point:
     # if the capture raises, the replay does not reproduce the eager gradients, or nothing comes back within
-    # --graph-timeout seconds, the eager line is printed as it stands.
-    if on_gpu and group is not None and has_act and scaling == 'strong' and not args.no_graph:
+    # --graph-timeout seconds, the eager line is printed as it stands.  Opt-in (--graph): a process that DIES inside a
+    # capture with N ranks of RCCL -- never run on this one-GPU-per-box pool -- would print nothing at all.
+    if on_gpu and group is not None and has_act and scaling == 'strong' and args.graph:
         def abandon():
             if out is not None:
                 out['hipgraph'] = {'error': 'no result within %g s: abandoned, the eager measurement stands' % args.graph_timeout}

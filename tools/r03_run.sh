@@ -3,7 +3,7 @@
 set -o pipefail
 OUT=gpurun_out/r03graph
 mkdir -p $OUT
-timeout -k 10 300 python bench.py --act-shape 32,512,56,56 --shard-path --graph-timeout 0.002 --steps 100 --warmup 30 --no-cpu-baseline 2>$OUT/err.txt > $OUT/line.json; echo "rc=$?"
+timeout -k 10 300 python bench.py --act-shape 32,512,56,56 --shard-path --graph --graph-timeout 0.002 --steps 100 --warmup 30 --no-cpu-baseline 2>$OUT/err.txt > $OUT/line.json; echo "rc=$?"
 python -c "
 import sys, json
 d = json.loads(open('$OUT/line.json').read().strip().splitlines()[-1])
