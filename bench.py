@@ -379,6 +379,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-n1', action='store_true',
                     help='N > 1: skip rank 0\'s single-GPU run of the whole tensor (no speedup_vs_n1 in the line)')
     ap.add_argument('--no-weak', action='store_true', help='N > 1: skip the weak-scaled side measurement')
+    ap.add_argument('--c10d-collectives', action='store_true',
+                    help='N > 1: keep the sharded step\'s collectives on torch.distributed (default: RCCL\'s C API from the '
+                         'C++ node when its start-up check against c10d passes)')
     ap.add_argument('--graph', action='store_true',
                     help='N > 1 (or --shard-path): also measure the step replayed from a HIP graph and report the faster '
                          'of the two.  Off by default: multi-rank RCCL inside a captured graph has not run on this '
@@ -573,11 +576,16 @@ def main():
 
     timer = None
     cpp_sharded = None
+    native_coll = False
     if on_gpu:
         from brevitas_amd import _native as nat
         timer = KernelTimer('bvq_fakequant_bwd', 'bvq_fakequant_fwd', 'bvq_stats', 'bvq_stats_fakequant_fwd')
         if group is not None:
             cpp_sharded = probe_sharded_node(group, device)
+            if cpp_sharded and not args.c10d_collectives:
+                # the node's two collectives through RCCL's C API on the compute stream (checked against c10d first)
+                from brevitas_amd.distributed import enable_native_collectives
+                native_coll = enable_native_collectives(group)
     settle_target = SETTLE_STEPS if args.settle_steps is None else args.settle_steps
     settle = 0 if args.no_settle else max(0, settle_target - args.warmup)
     has_act = kind in ('act_pc', 'act_pt', 'qconv', 'qlinear')
@@ -693,6 +701,8 @@ def main():
                        'parallelism': par,
                        'rccl_ranks': rccl_ranks,
                        'sharded_autograd_node': {True: 'C++ (collectives issued through c10d from the node)', False: 'Python Function (the C++ node failed its start-up probe)', None: None}[cpp_sharded] if group is not None else None,
+                       'collectives': (('RCCL C API from the C++ node, on the compute stream (checked against c10d at start-up)'
+                                        if native_coll else 'torch.distributed (c10d)') if group is not None else None),
                        'algorithmic_bytes_per_elem': m.bytes_per_elem},
             'hbm_frac_whole_step': round(m.bytes_per_elem * m.n_elem * world / (m.ms_per_step * 1e-3) / 1e9
                                          / (HBM_PEAK_GBS * world), 4),
@@ -779,6 +789,9 @@ def main():
         out['launch'] = 'eager'
     emit()
     if group is not None:
+        if native_coll:
+            from brevitas_amd.distributed import disable_native_collectives
+            disable_native_collectives(group)
         # the line is out: a teardown that does not come back (a rank gone after a failed capture) must not hold the job
         guard = threading.Timer(30.0, lambda: os._exit(0))
         guard.daemon = True

@@ -129,8 +129,8 @@ def build_autograd(force=False, verbose=False):
     from torch.utils import cpp_extension
     bdir = os.path.join(ROOT, 'build', 'autograd')
     os.makedirs(bdir, exist_ok=True)
-    cpp_extension.load(name='_bvq_autograd', sources=[src], build_directory=bdir, extra_cflags=['-O2', '-std=c++17'],
-                       extra_include_paths=[os.path.join(ROOT, 'include')],
+    cpp_extension.load(name='_bvq_autograd', sources=[src], build_directory=bdir, extra_cflags=['-O2', '-std=c++17', '-D__HIP_PLATFORM_AMD__=1'],
+                       extra_include_paths=[os.path.join(ROOT, 'include'), os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'include')],
                        extra_ldflags=['-ldl'], verbose=verbose, is_python_module=False)
     built = os.path.join(bdir, '_bvq_autograd.so')
     shutil.copyfile(built, AUTOGRAD_SO)

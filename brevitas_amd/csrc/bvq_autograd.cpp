@@ -17,8 +17,11 @@
 //                                  forward   float32 statistic, all-reduce(MAX), bvq_scale_from_stat_running,
 //                                            bvq_fakequant_fwd
 //                                  backward  bvq_fakequant_bwd_shard, all-gather, bvq_shard_unpack_deposit
-//     -- the two collectives are issued from here through c10d's C++ ProcessGroup (what torch.distributed.all_reduce /
-//     all_gather_into_tensor call underneath), so the step never returns to Python between its launches.
+//     -- the two collectives are issued from here, so the step never returns to Python between its launches: through
+//     RCCL's C API on the COMPUTE stream when the group has a native communicator (rccl_comm_init below: one
+//     ncclAllReduce / ncclAllGather call each, no work object, no hop to another stream and back -- c10d costs ~17-20 us
+//     of host time per call and two cross-stream event waits, profiles/r03_strong_scaling.md), else through c10d's C++
+//     ProcessGroup (what torch.distributed.all_reduce / all_gather_into_tensor call underneath).
 //
 // The C-ABI entries are the ones the Python route calls (include/bvq.h, included here: the descriptor layout and every
 // prototype come from that header), resolved with dlsym from the library the package has already loaded and checked
@@ -28,10 +31,12 @@
 // B/proxy/parameter_quant.py:83-89 and B/proxy/runtime_quant.py:80-84 -> RescalingIntQuant.forward,
 // B/core/quant/int.py:155-163.
 #include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the entry points are resolved from the RCCL torch has loaded
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <torch/extension.h>
 
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -105,6 +110,53 @@ struct GroupRef {
 std::unordered_map<std::string, GroupRef>& groups() {
   static auto* m = new std::unordered_map<std::string, GroupRef>();
   return *m;
+}
+
+// ---- RCCL's C API, from the library torch.distributed already runs on ------------------------------------------------
+struct Rccl {
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclAllReduce) all_reduce = nullptr;
+  decltype(&ncclAllGather) all_gather = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+  bool ok = false;
+};
+const Rccl& rccl() {
+  static const Rccl r = [] {
+    Rccl t;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so", "librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);  // the copy that is already in the process (torch's), never a second one
+      if (h) break;
+    }
+    if (!h) return t;
+    t.get_unique_id = reinterpret_cast<decltype(t.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
+    t.comm_init_rank = reinterpret_cast<decltype(t.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
+    t.comm_destroy = reinterpret_cast<decltype(t.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    t.all_reduce = reinterpret_cast<decltype(t.all_reduce)>(dlsym(h, "ncclAllReduce"));
+    t.all_gather = reinterpret_cast<decltype(t.all_gather)>(dlsym(h, "ncclAllGather"));
+    t.error_string = reinterpret_cast<decltype(t.error_string)>(dlsym(h, "ncclGetErrorString"));
+    t.ok = t.get_unique_id && t.comm_init_rank && t.comm_destroy && t.all_reduce && t.all_gather && t.error_string;
+    return t;
+  }();
+  return r;
+}
+void rccl_check(ncclResult_t rc, const char* what) {
+  if (rc != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + rccl().error_string(rc));
+}
+// native communicators by process-group name (brevitas_amd.distributed.enable_native_collectives)
+struct NativeComm {
+  ncclComm_t comm;
+  int world, rank;
+};
+std::unordered_map<std::string, NativeComm>& native_comms() {
+  static auto* m = new std::unordered_map<std::string, NativeComm>();
+  return *m;
+}
+const NativeComm* native_comm(const std::string& name) {
+  auto it = native_comms().find(name);
+  return it == native_comms().end() ? nullptr : &it->second;
 }
 
 std::vector<int64_t> desc_ints(const Params& p) {
@@ -267,7 +319,11 @@ class ActStatsFakeQuant : public torch::autograd::Function<ActStatsFakeQuant> {
     if (sharded) {
       // the statistic of the whole batch is the max over the shards (exact, order-independent)
       // (issued with one rank too: a one-rank group then exercises the same c10d / RCCL calls as N ranks)
-      {
+      if (const NativeComm* nc = native_comm(p.group->getGroupName())) {
+        rccl_check(rccl().all_reduce(stat32.data_ptr<float>(), stat32.data_ptr<float>(), (size_t)ch, ncclFloat32, ncclMax,
+                                     nc->comm, reinterpret_cast<hipStream_t>(st)),
+                   "ncclAllReduce");
+      } else {
         std::vector<at::Tensor> ts{stat32};
         c10d::AllreduceOptions opts;
         opts.reduceOp = c10d::ReduceOp::MAX;
@@ -341,7 +397,13 @@ class ActStatsFakeQuant : public torch::autograd::Function<ActStatsFakeQuant> {
                                         wsb, arr, arr_n, st),
               "bvq_fakequant_bwd_shard");
         at::Tensor gathered = at::empty({world * msg.numel()}, msg.options());
-        group->_allgather_base(gathered, msg)->wait();
+        if (const NativeComm* nc = native_comm(group->getGroupName())) {
+          rccl_check(rccl().all_gather(msg.data_ptr<double>(), gathered.data_ptr<double>(), (size_t)msg.numel(),
+                                       ncclFloat64, nc->comm, reinterpret_cast<hipStream_t>(st)),
+                     "ncclAllGather");
+        } else {
+          group->_allgather_base(gathered, msg)->wait();
+        }
         check(p_bvq_shard_unpack_deposit(d.x_dtype, x.data_ptr(), dx.data_ptr(), gathered.data_ptr<double>(), world,
                                          d.channels, rank, pos.data_ptr<int64_t>(), d.inner, sdt, qr[2], sdt, d.pre_op,
                                          nullptr, st),
@@ -462,7 +524,63 @@ py::object act_stats_fakequant(const at::Tensor& x, const at::Tensor& zp, const 
   return py::make_tuple(out[0], out[1], out[2]);
 }
 
+// ---- native communicators: set-up and a probe, called from brevitas_amd/distributed.py ---------------------------------
+py::object rccl_unique_id() {
+  if (!rccl().ok) return py::none();
+  ncclUniqueId id;
+  rccl_check(rccl().get_unique_id(&id), "ncclGetUniqueId");
+  return py::bytes(reinterpret_cast<const char*>(&id), sizeof(id));
+}
+// every rank of the group, with rank 0's id; the caller has made the rank's device current
+void rccl_comm_init(const std::string& name, const std::string& id_bytes, int world, int rank) {
+  if (!rccl().ok) throw std::runtime_error("RCCL's C API is not available in this process");
+  if (id_bytes.size() != sizeof(ncclUniqueId)) throw std::runtime_error("rccl_comm_init: bad unique id");
+  ncclUniqueId id;
+  std::memcpy(&id, id_bytes.data(), sizeof(id));
+  auto it = native_comms().find(name);
+  if (it != native_comms().end()) {
+    rccl().comm_destroy(it->second.comm);
+    native_comms().erase(it);
+  }
+  ncclComm_t comm = nullptr;
+  {
+    py::gil_scoped_release nogil;
+    rccl_check(rccl().comm_init_rank(&comm, world, id, rank), "ncclCommInitRank");
+  }
+  native_comms()[name] = NativeComm{comm, world, rank};
+}
+void rccl_comm_drop(const std::string& name) {
+  auto it = native_comms().find(name);
+  if (it == native_comms().end()) return;
+  rccl().comm_destroy(it->second.comm);
+  native_comms().erase(it);
+}
+bool rccl_comm_active(const std::string& name) { return native_comm(name) != nullptr; }
+// the two calls the node makes, on the caller's current stream (probe and tests)
+void rccl_all_reduce_max(const std::string& name, at::Tensor t, int64_t stream) {
+  const NativeComm* nc = native_comm(name);
+  if (!nc || t.scalar_type() != at::kFloat || !t.is_contiguous()) throw std::runtime_error("rccl_all_reduce_max: bad call");
+  rccl_check(rccl().all_reduce(t.data_ptr<float>(), t.data_ptr<float>(), (size_t)t.numel(), ncclFloat32, ncclMax, nc->comm,
+                               reinterpret_cast<hipStream_t>(stream)),
+             "ncclAllReduce");
+}
+void rccl_all_gather_f64(const std::string& name, at::Tensor msg, at::Tensor out, int64_t stream) {
+  const NativeComm* nc = native_comm(name);
+  if (!nc || msg.scalar_type() != at::kDouble || out.scalar_type() != at::kDouble || !msg.is_contiguous() ||
+      !out.is_contiguous() || out.numel() != msg.numel() * nc->world)
+    throw std::runtime_error("rccl_all_gather_f64: bad call");
+  rccl_check(rccl().all_gather(msg.data_ptr<double>(), out.data_ptr<double>(), (size_t)msg.numel(), ncclFloat64, nc->comm,
+                               reinterpret_cast<hipStream_t>(stream)),
+             "ncclAllGather");
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("rccl_unique_id", &rccl_unique_id, "ncclGetUniqueId as bytes (None: RCCL's C API is not in this process)");
+  m.def("rccl_comm_init", &rccl_comm_init, "ncclCommInitRank for the process group of this name");
+  m.def("rccl_comm_drop", &rccl_comm_drop, "destroy the native communicator of this group, if any");
+  m.def("rccl_comm_active", &rccl_comm_active, "the group of this name has a native communicator");
+  m.def("rccl_all_reduce_max", &rccl_all_reduce_max, "float32 all-reduce(MAX) in place on the given stream");
+  m.def("rccl_all_gather_f64", &rccl_all_gather_f64, "float64 all-gather on the given stream");
   m.def("init", &init, "resolve libbvq.so, check its ABI version, register the python fallback of the backward");
   m.def("abi_version", &abi_version, "BVQ_ABI_VERSION of the include/bvq.h this module was built against");
   m.def("stats_fakequant", &stats_fakequant, "AbsMax -> scale -> IntQuant in one launch (weights), autograd node in C++");

@@ -6,7 +6,8 @@ shards.  So the path shards with NO data-path collective except
   forward   one all-reduce(MAX) of the per-channel (or whole-tensor) abs-max     <= 4 KB
   backward  one all-gather of [scale-gradient partial sums | tie ownership]       <= 8 KB x ranks
 
-over RCCL/xGMI (backend "nccl" on ROCm; "gloo" works for CPU tensors in tests).  Both are
+over RCCL/xGMI (backend "nccl" on ROCm; "gloo" works for CPU tensors in tests; enable_native_collectives() lets the
+C++ node of the sharded quantizer issue both through RCCL's C API on the compute stream).  Both are
 latency-bound messages; they sit between the statistic kernel and the quantize kernel (resp. between
 the backward kernel and the tiny deposit kernel), so no extra pass over the tensor is made.
 
@@ -48,6 +49,65 @@ def shard_over_batch(quantizer, group=None):
         elif getattr(m, 'bvq_is_stat', False):
             raise NotImplementedError('%s has no batch-sharded form' % type(m).__name__)
     return quantizer
+
+
+def enable_native_collectives(group=None) -> bool:
+    """Give `group` (default: the world group) a communicator of its own on RCCL's C API, used by the C++ autograd node
+    of the batch-sharded quantizer (brevitas_amd/csrc/bvq_autograd.cpp): its all-reduce and all-gather are then ONE
+    ncclAllReduce / ncclAllGather call each on the compute stream -- no c10d work object (~17-20 us of host time per
+    call), no hop to RCCL's side stream and back (two event waits around a 4 KB message).  Collective: every rank of
+    the group calls it, with its device current.  The communicator is checked against torch.distributed before it is
+    kept: an all-reduce(MAX) and an all-gather of rank-dependent data must equal c10d's results on every rank.
+    -> True (in use) / False (not available or failed the check: the node keeps issuing its collectives through c10d)"""
+    from brevitas_amd.core.quant import _fused
+    if not dist.is_initialized():
+        raise RuntimeError('enable_native_collectives: torch.distributed is not initialised')
+    group = group if group is not None else dist.group.WORLD
+    fast = _fused._fast_module()
+    if not fast or dist.get_backend(group) != 'nccl' or not torch.cuda.is_available():
+        return False
+    rank, world = world_of(group)
+    name = group.group_name
+    dev = torch.device('cuda', torch.cuda.current_device())
+    ok = True
+    try:
+        box = [fast.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0), group=group)
+        if box[0] is None:
+            return False  # (the same answer on every rank: rank 0's)
+        fast.rccl_comm_init(name, box[0], world, rank)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        # the node's two calls on rank-dependent data, against c10d
+        a = (torch.arange(64, device=dev, dtype=torch.float32) * (1 + rank) % 7) - rank
+        want = a.clone()
+        dist.all_reduce(want, op=dist.ReduceOp.MAX, group=group)
+        fast.rccl_all_reduce_max(name, a, st)
+        m = torch.arange(16, device=dev, dtype=torch.float64) + 1000.0 * rank
+        got = torch.empty(16 * world, device=dev, dtype=torch.float64)
+        fast.rccl_all_gather_f64(name, m, got, st)
+        wantg = torch.empty_like(got)
+        dist.all_gather_into_tensor(wantg, m, group=group)
+        ok = bool(torch.equal(a, want)) and bool(torch.equal(got, wantg))
+    except Exception:  # an entry point missing, an RCCL error: keep c10d
+        ok = False
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    ok = bool(flag.item() > 0.5)
+    if not ok:
+        try:
+            fast.rccl_comm_drop(name)
+        except Exception:
+            pass
+    return ok
+
+
+def disable_native_collectives(group=None) -> None:
+    """drop the native communicator of `group` (before destroy_process_group, or to go back to c10d)"""
+    from brevitas_amd.core.quant import _fused
+    group = group if group is not None else dist.group.WORLD
+    fast = _fused._fast_module()
+    if fast:
+        fast.rccl_comm_drop(group.group_name)
 
 
 def world_of(group) -> Tuple[int, int]:

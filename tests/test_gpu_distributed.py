@@ -238,3 +238,52 @@ def test_wide_stepwise_select_over_two_shards_on_one_device(dtype, split):
         src = full.float().abs() if abs_key else full.float()
         want = src.kthvalue(min(max(k, 1), n)).values
         assert torch.equal(vals[0].float().reshape(()), want) and torch.equal(vals[1], vals[0]), (abs_key, rule, q)
+
+
+@pytest.mark.parametrize('per_channel', [True, False], ids=['per_channel', 'per_tensor'])
+def test_sharded_step_replays_from_a_hip_graph(nccl_world1, per_channel):
+    """the whole sharded step -- statistic, all-reduce, scale, quantizer, backward, all-gather, deposit -- captured once
+    into a HIP graph and replayed: bench.graphed_run checks the replayed gradients against the eager step bit for bit
+    before it times anything (a launch-bound step: one rank of an 8-way split, profiles/r03_strong_scaling.md)"""
+    import bench
+    job = bench.Job('act_pc' if per_channel else 'act_pt', torch.bfloat16, torch.device(DEV), nccl_world1, 0,
+                    act_shape=(4, 64, 28, 28))
+    elapsed, note = bench.graphed_run(job, steps=5, warmup=2, world=1, device=torch.device(DEV))
+    assert elapsed is not None and elapsed > 0, note
+    assert 'verified' in note
+
+
+def test_native_collectives_equal_c10d(nccl_world1):
+    """the sharded quantizer with its two collectives issued through RCCL's C API from the C++ node
+    (brevitas_amd.distributed.enable_native_collectives: communicator set-up, the check against c10d, the node's calls)
+    equals the same quantizer on c10d and the unsharded one bit for bit; it also replays from a HIP graph"""
+    import bench
+    from brevitas_amd.core.quant import _fused
+    from brevitas_amd.distributed import disable_native_collectives, enable_native_collectives
+    if not _fused._fast_module():
+        pytest.skip('the C++ autograd node is not built')
+    torch.manual_seed(7)
+    x = torch.randn(8, 32, 28, 28, device=DEV, dtype=torch.bfloat16)
+    g = torch.randn_like(x)
+
+    def run(group):
+        q = bench.build_quantizer(32, True, torch.device(DEV), group)
+        xi = x.clone().requires_grad_(True)
+        y, scale = q(xi)[:2]
+        y.backward(g)
+        return y.detach(), scale.detach(), xi.grad
+
+    plain = run(None)
+    c10d = run(nccl_world1)
+    assert enable_native_collectives(nccl_world1) is True
+    try:
+        assert _fused._fast_module().rccl_comm_active(nccl_world1.group_name)
+        native = run(nccl_world1)
+        for a, b, c, what in zip(plain, c10d, native, ('y', 'scale', 'dx')):
+            assert torch.equal(a, b) and torch.equal(a, c), what
+        job = bench.Job('act_pc', torch.bfloat16, torch.device(DEV), nccl_world1, 0, act_shape=(4, 64, 28, 28))
+        elapsed, note = bench.graphed_run(job, steps=5, warmup=2, world=1, device=torch.device(DEV))
+        assert elapsed is not None and 'verified' in note, note
+    finally:
+        disable_native_collectives(nccl_world1)
+    assert not _fused._fast_module().rccl_comm_active(nccl_world1.group_name)

@@ -9,8 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUNS = [('act_per_channel_bf16', []), ('act_per_tensor_bf16', []), ('act_per_channel_f32', []), ('weight_conv_int8', ['--steps', '2000', '--warmup', '200']),
         ('weight_linear_int4', ['--steps', '1000', '--warmup', '100']),
         # config 4 on ONE GPU of the eight it names: that GPU's 128 rows of the batch of 1024 (as in rounds 1 and 2)
-        ('qconv_layer3', ['--steps', '1000', '--warmup', '100', '--act-shape', '128,1024,14,14']),
-        ('qlinear_8192', ['--steps', '500', '--warmup', '50']), ('act_per_channel_bf16', ['--shard-path']),
+        ('qconv_layer3', ['--steps', '1000', '--warmup', '100', '--act-shape', '128,1024,14,14', '--graph-replay']),
+        ('qlinear_8192', ['--steps', '500', '--warmup', '50', '--graph-replay']), ('act_per_channel_bf16', ['--shard-path']),
+        # one rank's shard of the 8-way strong split, collectives issued by a one-rank RCCL group, eager and replayed
+        ('act_per_channel_bf16', ['--act-shape', '32,512,56,56', '--shard-path', '--graph-replay']),
         ('act_per_channel_bf16', ['--steps', '20', '--warmup', '5']),
         # the same call WITHOUT the 35 untimed clock-settling steps bench.py runs before the warm-up by default
         ('act_per_channel_bf16', ['--steps', '20', '--warmup', '5', '--no-settle'])]
