@@ -39,6 +39,9 @@ def _worker(rank, world, port, per_channel, stat_kind, q):
             if group is not None:
                 shard_over_batch(qz, group)
             return qz
+        # (native collectives are RCCL's: on a gloo group every rank is told so and nothing changes)
+        from brevitas_amd.distributed import enable_native_collectives
+        assert enable_native_collectives() is False
         full, shard = make(None), make(dist.group.WORLD)
         for step in range(2):   # the second step also exercises the running-statistics update
             xf = x.clone().requires_grad_(True)
