@@ -319,6 +319,12 @@ struct ColsPlan {
   int64_t units;    // nrb * strips
 };
 // no_partials: the caller's kernel writes no per-unit partial rows (more, shorter units pay then)
+// columns of a 16-bit type a lane of the column-mapped BACKWARD holds (8 = one 16-byte load per row, 4 = an 8-byte
+// load: half the per-column state -- scale, reciprocal, partial sum, running maximum -- in registers)
+#ifndef BVQ_COLS_TEAM_VEC16
+#define BVQ_COLS_TEAM_VEC16 4
+#endif
+constexpr int kColsTeamVec16 = BVQ_COLS_TEAM_VEC16;
 // team: the caller's kernel gives a unit to a whole workgroup (four waves sharing the rows, partials combined on chip)
 ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bool no_partials = false,
                    bool team = false);

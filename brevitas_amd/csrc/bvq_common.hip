@@ -132,7 +132,8 @@ ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bo
   static const int enabled = env_flag("BVQ_COLS", 1);
   ColsPlan p = {};
   const int el = dtype == BVQ_F32 ? 4 : 2;
-  const int vec = 16 / el;
+  // (the backward's workgroup units hold kColsTeamVec16 columns of a 16-bit type per lane: bvq_common.h)
+  const int vec = team && el == 2 ? kColsTeamVec16 : 16 / el;
   // short inner runs: from 256 bytes per channel row on, the row-mapped units stream well -- unless the rows are
   // not 16-byte multiples (14x14 maps of a 16-bit type: 392 bytes), where the row-mapped route drops to 8- or
   // 2-byte accesses: [1024,1024,14,14] bf16 forward 3.0 -> 5.5 TB/s, abs-max 3.3 -> 5.1 on this route
@@ -142,7 +143,7 @@ ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bo
   const bool ragged_rows = row_bytes % 16 != 0 && row_bytes < 4096 && outer >= 64;
   if (!enabled || channels < 2 || inner < 1 || outer < 2 || !(short_rows || ragged_rows)) return p;
   const int64_t L = channels * inner;
-  if (L % vec != 0 || L / vec > (1 << 30)) return p;
+  if (L % (16 / el) != 0 || L / vec > (1 << 30)) return p;  // (the same layouts for every kernel: rows of 16-byte chunks)
   p.rows = outer;
   p.L = L;
   p.vec = vec;
@@ -170,13 +171,14 @@ ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bo
   if (rows_for_that > rb) rb = ((rows_for_that + p.rpp - 1) / p.rpp) * p.rpp;
   if (team && !no_partials && !env_units) {
     // a workgroup's rows by count, not by a unit total: short blocks keep the resident workgroups' window of memory
-    // small, which is what these kernels' bandwidth follows (profiles/r03_column_mapped.txt: 16-bit types best at
-    // 64..128 rows on every layout measured, float32 at 16..48) -- down to where a wave's set-up (its columns' scales,
-    // reciprocals) stops being hidden: the 16-bit kernel holds 8 columns per lane in ~100 registers, four waves per
-    // SIMD, and falls off below ~12 rows per wave; the float32 one runs seven waves.
-    // One partial row of 4 L bytes per block: 1/96 (1/16) of a block's 3 x 2 L (3 x 4 L) bytes per row = 0.7 % (2 %).
+    // small, which is what these kernels' bandwidth follows (profiles/r03_column_mapped.txt) -- down to where a wave's
+    // set-up (its columns' scales, reciprocals) stops being hidden: float32 (4 columns per lane, seven waves per SIMD)
+    // is best at 16 rows; bf16 at 48 and float16 -- whose arithmetic is half again as long -- at 96, both with 4
+    // columns per lane and eight waves per SIMD (with 8 columns per lane in ~104 registers, four waves per SIMD, both
+    // wanted 96 and streamed 3-8 % slower).
+    // One partial row of 4 L bytes per block: 1/48 (1/16) of a block's 3 x 2 L (3 x 4 L) bytes per row = 1.4 % (2 %).
     static const int env_rows = env_flag("BVQ_COLS_TEAM_ROWS", 0);  // experiments only
-    const int64_t groups = env_rows > 0 ? env_rows : (el == 2 ? 96 : 16);
+    const int64_t groups = env_rows > 0 ? env_rows : (dtype == BVQ_BF16 ? 48 : dtype == BVQ_F16 ? 96 : 16);
     rb = groups * (int64_t)p.rpp;
   }
   // a lane's row counter within a unit fits 16 bits (the backward packs it next to a 16-bit key)

@@ -250,9 +250,9 @@ struct ColsQuantArgs {
 };
 
 // what a lane needs to know about its VEC columns, loaded once per unit
-template <typename T>
+template <typename T, int V = elem<T>::vec>
 struct ColsLane {
-  static constexpr int VEC = elem<T>::vec;
+  static constexpr int VEC = V;
   int64_t row0, row_end;
   int64_t blk0;  // first row of the unit's row block (wave-uniform)
   int32_t chunk, sub;

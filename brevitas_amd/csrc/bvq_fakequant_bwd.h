@@ -557,10 +557,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96), amdgpu_
 // Arg-max search of the statistic: the hot loop keeps each column's largest |x| key only (packed unsigned 16-bit max:
 // 2 instructions per pair); a lane one of whose columns attains its channel's statistic -- about one lane per channel
 // in the whole launch -- walks its rows once more, cold, and takes the first row that shows it.
+template <typename T>
+constexpr int kColsBwdVec = sizeof(T) == 2 ? kColsTeamVec16 : elem<T>::vec;
+
 template <typename T, int RM, bool NT, bool ZP0, bool FAST, bool PRE>
-__device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const ColsLane<T>& ln, float qmin, float qmax,
-                                              float* sh_ds) {
-  constexpr int VEC = elem<T>::vec;
+__device__ __forceinline__ void cols_bwd_rows(const ColsQuantArgs& a, const ColsLane<T, kColsBwdVec<T>>& ln, float qmin,
+                                              float qmax, float* sh_ds) {
+  constexpr int VEC = kColsBwdVec<T>;
   constexpr bool kSame16 = sizeof(T) == 2;
   typedef short i16x2 __attribute__((ext_vector_type(2)));
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -720,7 +723,7 @@ template <typename T, int RM, bool NT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BVQ_COLS_BWD_WAVES, 8))) void fakequant_bwd_cols_kernel(
     ColsQuantArgs a) {
   __shared__ float sh_ds[(kWavesPerBlock - 1) * 8 * kWave];  // waves 1..3 hand their column sums to wave 0
-  ColsLane<T> ln;
+  ColsLane<T, kColsBwdVec<T>> ln;
   if (!ln.init(a, true) || !ln.active) return;
   const float qmin = rnd<T>(a.qmin), qmax = rnd<T>(a.qmax);
 #define BVQ_COLS_BWD(ZP0, FAST)                                   \
