@@ -379,6 +379,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-n1', action='store_true',
                     help='N > 1: skip rank 0\'s single-GPU run of the whole tensor (no speedup_vs_n1 in the line)')
     ap.add_argument('--no-weak', action='store_true', help='N > 1: skip the weak-scaled side measurement')
+    ap.add_argument('--share-device', action='store_true',
+                    help='developer option: every rank on device 0, exchanging over gloo -- a rehearsal of the N > 1 control '
+                         'flow (rank 0 alone first, strong split, weak) on a one-GPU box; its numbers mean nothing')
     ap.add_argument('--c10d-collectives', action='store_true',
                     help='N > 1: keep the sharded step\'s collectives on torch.distributed (default: RCCL\'s C API from the '
                          'C++ node when its start-up check against c10d passes)')
@@ -538,6 +541,10 @@ def main():
     if on_gpu:
         if not torch.cuda.is_available():
             raise SystemExit('bench.py needs a ROCm device (the product path has no CPU fallback for device tensors)')
+        if args.share_device:
+            if args.backend != 'gloo':
+                raise SystemExit('--share-device goes with --backend gloo (RCCL refuses two ranks on one device)')
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         device = torch.device('cuda', local_rank)
     else:
@@ -552,7 +559,7 @@ def main():
         import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        kw = {'device_id': device} if on_gpu else {}
+        kw = {'device_id': device} if on_gpu and args.backend == 'nccl' else {}
         if world == 1:
             os.environ.setdefault('MASTER_PORT', str(free_port()))
             dist.init_process_group(args.backend, rank=0, world_size=1, timeout=datetime.timedelta(seconds=600), **kw)

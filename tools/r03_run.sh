@@ -3,8 +3,12 @@
 set -o pipefail
 OUT=gpurun_out/r03final
 mkdir -p $OUT
-: > $OUT/fuzz_soak.txt
-for seed in 20261005 31337; do
-  BVQ_FUZZ_CASES=1300 BVQ_FUZZ_SEED=$seed timeout -k 10 900 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -2 | sed "s/^/seed $seed, 1300 cases: /" >> $OUT/fuzz_soak.txt || { cat $OUT/fuzz_soak.txt; exit 1; }
-done
-cat $OUT/fuzz_soak.txt
+timeout -k 10 500 python bench.py --gpus 2 --backend gloo --share-device --steps 20 --warmup 5 > $OUT/rehearsal_n2.json 2> $OUT/rehearsal_n2.err; echo "rc=$?"
+tail -5 $OUT/rehearsal_n2.err
+python - <<'PY'
+import json
+d = json.loads(open('gpurun_out/r03final/rehearsal_n2.json').read().strip().splitlines()[-1])
+keep = {k: d[k] for k in ('value', 'n_gpus', 'ms_per_step', 'scaling', 'speedup_vs_n1', 'launch') if k in d}
+keep['n1'] = d.get('n1'); keep['weak'] = d.get('weak'); keep['config'] = {k: d['config'][k] for k in ('tensors_per_gpu', 'parallelism', 'rccl_ranks', 'sharded_autograd_node', 'collectives')}
+print(json.dumps(keep, indent=1))
+PY
