@@ -292,13 +292,23 @@ def graph_replay_us(job, iters=200):
     return (time.perf_counter() - t0) / iters * 1e6
 
 
-def graphed_run(job, steps, warmup, world, device):
+def graphed_run(job, steps, warmup, world, device, group=None):
     """The step captured ONCE into a HIP graph (kernels and the two collectives alike: every launch goes to the capture
     stream, nothing is read back) and replayed: warm-up replays untimed, then `steps` replays between barriers.
     Before anything is timed the replay is checked against the eager step: the gradient it leaves in x.grad must equal
     the eager one bit for bit on EVERY rank, or the graph is not used.
+    A sharded step is captured only when its collectives are direct RCCL calls on the capture stream
+    (brevitas_amd.distributed.enable_native_collectives): torch.distributed's watchdog thread may query an event
+    recorded in the capturing stream, which HIP answers with hipErrorCapturedEvent and the thread with terminate() --
+    seen once in a few runs on this image.
     -> (max-over-ranks seconds or None, note)"""
     import torch.distributed as dist
+    if group is not None:
+        from brevitas_amd.core.quant import _fused
+        fast = _fused._fast_module()
+        if not fast or not fast.rccl_comm_active(group.group_name):
+            return None, ('not captured: the collectives of this group go through torch.distributed, whose watchdog thread '
+                          'may query a captured event and abort the process')
 
     def agree(flag):  # 1.0 only if every rank says so
         t = torch.tensor([1.0 if flag else 0.0], device=device)
@@ -638,7 +648,8 @@ def main():
     main_m = Measurement(job, elapsed, args.steps, world, timer)
     replay_us = None
     graph_error = None
-    if world == 1 and on_gpu and (kind in ('weight_conv', 'weight_linear') or args.graph_replay):
+    if world == 1 and on_gpu and (kind in ('weight_conv', 'weight_linear') or args.graph_replay) \
+            and (group is None or native_coll):   # (c10d collectives are never captured: see graphed_run)
         try:
             replay_us = graph_replay_us(job)
         except Exception as e:  # developer option on routes that may not capture (collectives): say so, keep the line
@@ -767,7 +778,7 @@ def main():
         failed = False
         try:
             job = Job(kind, dtype, device, group, rank, act_shape=shard_shape)
-            g_elapsed, note = graphed_run(job, args.steps, args.warmup, world, device)
+            g_elapsed, note = graphed_run(job, args.steps, args.warmup, world, device, group)
             g_m = Measurement(job, g_elapsed, args.steps, world) if g_elapsed else None
             del job
         except Exception as e:

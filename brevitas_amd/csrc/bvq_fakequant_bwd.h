@@ -81,11 +81,12 @@ __device__ __forceinline__ float add_rounded_pair_bf16(float acc, f2 v) {
 // = 0x00003f80 is emitted as the inline constant "1.0", which the instruction reads as 0x3f800000 = {0, 1.0bf16}
 // (ROCm 7.2 / gfx950: both sums then received the pair's second element).  make_dot_sel() once per kernel.
 struct DotSel {
-  uint32_t lo, hi;
+  uint32_t lo, hi;      // bf16 {1, 0}, {0, 1}
+  uint32_t lo16, hi16;  // float16 {1, 0}, {0, 1}
 };
 __device__ __forceinline__ DotSel make_dot_sel() {
-  DotSel d = {0x00003f80u, 0x3f800000u};
-  asm volatile("" : "+s"(d.lo), "+s"(d.hi));
+  DotSel d = {0x00003f80u, 0x3f800000u, 0x00003c00u, 0x3c000000u};
+  asm volatile("" : "+s"(d.lo), "+s"(d.hi), "+s"(d.lo16), "+s"(d.hi16));
   return d;
 }
 __device__ __forceinline__ f2 add_rounded_lanes_bf16(f2 acc, f2 v, const DotSel& sel) {
@@ -93,6 +94,22 @@ __device__ __forceinline__ f2 add_rounded_lanes_bf16(f2 acc, f2 v, const DotSel&
   const bf16x2 p = __builtin_convertvector(v, bf16x2);
   return f2{__builtin_amdgcn_fdot2_f32_bf16(p, __builtin_bit_cast(bf16x2, sel.lo), acc.x, false),
             __builtin_amdgcn_fdot2_f32_bf16(p, __builtin_bit_cast(bf16x2, sel.hi), acc.y, false)};
+}
+// float16: the same with v_dot2_f32_f16 (the selectors kept out of the compiler's sight like the bf16 ones)
+#ifndef BVQ_BWD_LEAN_F16
+#define BVQ_BWD_LEAN_F16 1
+#endif
+// acc + RN_f16(v.x) + RN_f16(v.y)   ({1, 1} = 0x3c003c00 is no inline constant: emitted as a literal)
+__device__ __forceinline__ float add_rounded_pair_f16(float acc, f2 v) {
+  typedef f16_t f16x2 __attribute__((ext_vector_type(2)));
+  const f16x2 ones = {(f16_t)1.0f, (f16_t)1.0f};
+  return __builtin_amdgcn_fdot2(__builtin_convertvector(v, f16x2), ones, acc, false);
+}
+__device__ __forceinline__ f2 add_rounded_lanes_f16(f2 acc, f2 v, const DotSel& sel) {
+  typedef f16_t f16x2 __attribute__((ext_vector_type(2)));
+  const f16x2 p = __builtin_convertvector(v, f16x2);
+  return f2{__builtin_amdgcn_fdot2(p, __builtin_bit_cast(f16x2, sel.lo16), acc.x, false),
+            __builtin_amdgcn_fdot2(p, __builtin_bit_cast(f16x2, sel.hi16), acc.y, false)};
 }
 // MIX: the caller adds the two halves of ds_acc up in the end (row-mapped units: one channel per wave), so the sums
 // of the pair's elements may share an accumulator; otherwise ds_acc.x / .y stay the sums of element x / y.
@@ -136,6 +153,13 @@ __device__ __forceinline__ f2 bwd_elem2(f2 xf, f2 gf, const Div& div, S s, S z, 
     } else if constexpr (kLean && elem<CT>::id == BVQ_BF16) {
       ds_acc = add_rounded_lanes_bf16(ds_acc, gf * t5, sel);
       ds_acc = add_rounded_lanes_bf16(ds_acc, -dt * rnd2<CT>(div(t1)), sel);
+    } else if constexpr (kLean && BVQ_BWD_LEAN_F16 && elem<CT>::id == BVQ_F16 && MIX) {
+      const float a1 = add_rounded_pair_f16(ds_acc.x, gf * t5);
+      const float a2 = add_rounded_pair_f16(ds_acc.y, -dt * rnd2<CT>(div(t1)));
+      ds_acc = f2{a1, a2};
+    } else if constexpr (kLean && BVQ_BWD_LEAN_F16 && elem<CT>::id == BVQ_F16) {
+      ds_acc = add_rounded_lanes_f16(ds_acc, gf * t5, sel);
+      ds_acc = add_rounded_lanes_f16(ds_acc, -dt * rnd2<CT>(div(t1)), sel);
     } else {
       const f2 term1 = rnd2<CT>(gf * t5);
       const f2 term2 = rnd2<CT>(-dt * rnd2<CT>(div(t1)));
