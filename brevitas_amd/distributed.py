@@ -69,30 +69,48 @@ def enable_native_collectives(group=None) -> bool:
     rank, world = world_of(group)
     name = group.group_name
     dev = torch.device('cuda', torch.cuda.current_device())
+    def agree(flag: bool) -> bool:  # True only if every rank says so (a torch.distributed collective: same order on every rank)
+        t = torch.tensor([1.0 if flag else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(t.item() > 0.5)
+
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = fast.rccl_unique_id()
+        except Exception:
+            box[0] = None
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0), group=group)
+    if box[0] is None:
+        return False  # (the same answer on every rank: rank 0's)
     ok = True
     try:
-        box = [fast.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0), group=group)
-        if box[0] is None:
-            return False  # (the same answer on every rank: rank 0's)
         fast.rccl_comm_init(name, box[0], world, rank)
-        st = torch.cuda.current_stream(dev).cuda_stream
-        # the node's two calls on rank-dependent data, against c10d
-        a = (torch.arange(64, device=dev, dtype=torch.float32) * (1 + rank) % 7) - rank
-        want = a.clone()
-        dist.all_reduce(want, op=dist.ReduceOp.MAX, group=group)
-        fast.rccl_all_reduce_max(name, a, st)
-        m = torch.arange(16, device=dev, dtype=torch.float64) + 1000.0 * rank
-        got = torch.empty(16 * world, device=dev, dtype=torch.float64)
-        fast.rccl_all_gather_f64(name, m, got, st)
-        wantg = torch.empty_like(got)
-        dist.all_gather_into_tensor(wantg, m, group=group)
-        ok = bool(torch.equal(a, want)) and bool(torch.equal(got, wantg))
-    except Exception:  # an entry point missing, an RCCL error: keep c10d
+    except Exception:  # an RCCL error at set-up: keep c10d
         ok = False
-    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    ok = bool(flag.item() > 0.5)
+    if not agree(ok):
+        try:
+            fast.rccl_comm_drop(name)
+        except Exception:
+            pass
+        return False
+    # the node's two calls on rank-dependent data against torch.distributed's: the reference results first (every rank,
+    # outside any try), then the direct calls
+    st = torch.cuda.current_stream(dev).cuda_stream
+    a = (torch.arange(64, device=dev, dtype=torch.float32) * (1 + rank) % 7) - rank
+    want = a.clone()
+    dist.all_reduce(want, op=dist.ReduceOp.MAX, group=group)
+    m = torch.arange(16, device=dev, dtype=torch.float64) + 1000.0 * rank
+    wantg = torch.empty(16 * world, device=dev, dtype=torch.float64)
+    dist.all_gather_into_tensor(wantg, m, group=group)
+    try:
+        got = torch.empty_like(wantg)
+        fast.rccl_all_reduce_max(name, a, st)
+        fast.rccl_all_gather_f64(name, m, got, st)
+        ok = bool(torch.equal(a, want)) and bool(torch.equal(got, wantg))
+    except Exception:
+        ok = False
+    ok = agree(ok)
     if not ok:
         try:
             fast.rccl_comm_drop(name)
