@@ -399,6 +399,8 @@ def parse_args(argv=None):
                     help='N > 1 (or --shard-path): also measure the step replayed from a HIP graph and report the faster '
                          'of the two.  Off by default: multi-rank RCCL inside a captured graph has not run on this '
                          'pool, and a process that dies inside the capture prints nothing')
+    ap.add_argument('--native-timeout', type=float, default=120.0,
+                    help='N > 1: seconds the re-run on direct RCCL calls may take before the line is printed without it')
     ap.add_argument('--graph-timeout', type=float, default=120.0,
                     help='N > 1: seconds the HIP-graph measurement may take before the eager line is printed without it')
     ap.add_argument('--launch-timeout', type=float, default=900.0,
@@ -599,8 +601,10 @@ def main():
         timer = KernelTimer('bvq_fakequant_bwd', 'bvq_fakequant_fwd', 'bvq_stats', 'bvq_stats_fakequant_fwd')
         if group is not None:
             cpp_sharded = probe_sharded_node(group, device)
-            if cpp_sharded and not args.c10d_collectives:
-                # the node's two collectives through RCCL's C API on the compute stream (checked against c10d first)
+            if cpp_sharded and not args.c10d_collectives and world == 1:
+                # the node's two collectives through RCCL's C API on the compute stream (checked against c10d first).
+                # With N > 1 this happens AFTER the whole run has been measured on torch.distributed's collectives
+                # (below): a second communicator between N ranks has never been set up on this pool.
                 from brevitas_amd.distributed import enable_native_collectives
                 native_coll = enable_native_collectives(group)
     settle_target = SETTLE_STEPS if args.settle_steps is None else args.settle_steps
@@ -757,6 +761,63 @@ def main():
                 emitted.append(True)
                 sys.stdout.flush()
                 os.write(result_fd, (json.dumps(out) + '\n').encode())
+
+    # ---- N > 1: the strong split once more with the two collectives as direct RCCL calls -----------------------------------
+    # Everything above ran on torch.distributed's collectives and is complete.  Now the group gets a communicator of its
+    # own (checked against torch.distributed on every rank) and the strong job runs again; the line takes the faster of
+    # the two and says which (`config.collectives`, the other one under "c10d" / "native_collectives").  If the set-up
+    # fails its check, raises, or nothing comes back within --native-timeout seconds, the line is printed as it stands.
+    if on_gpu and group is not None and world > 1 and cpp_sharded and has_act and scaling == 'strong' \
+            and not args.c10d_collectives:
+        def abandon_native():
+            if out is not None:
+                out['native_collectives'] = {'error': 'no result within %g s: abandoned, the run on torch.distributed\'s '
+                                                      'collectives stands' % args.native_timeout}
+                out['launch'] = 'eager'
+            emit()
+            os._exit(0)
+        watchdog = threading.Timer(args.native_timeout, abandon_native)
+        watchdog.daemon = True
+        watchdog.start()
+        n_m, note, failed = None, None, False
+        try:
+            from brevitas_amd.distributed import enable_native_collectives
+            native_coll = enable_native_collectives(group)
+            if native_coll:
+                job = Job(kind, dtype, device, group, rank, act_shape=shard_shape)
+                e = timed_run(job, args.steps, args.warmup, 0, world, device, None, on_gpu=True)
+                n_m = Measurement(job, e, args.steps, world)
+                del job
+                free()
+            else:
+                note = 'set-up or its check against torch.distributed failed on some rank'
+        except Exception as exc:
+            failed, n_m = True, None
+            note = 'failed: %s: %s' % (type(exc).__name__, str(exc).splitlines()[0][:160])
+        watchdog.cancel()
+        if out is not None:
+            if n_m is not None:
+                c10d = {'value': out['value'], 'ms_per_step': out['ms_per_step']}
+                native = {'value': round(n_m.value, 3), 'ms_per_step': round(n_m.ms_per_step, 4)}
+                if n_m.value > out['value']:
+                    out['value'], out['ms_per_step'] = native['value'], native['ms_per_step']
+                    out['hbm_frac_whole_step'] = round(n_m.bytes_per_elem * n_m.n_elem * world / (n_m.ms_per_step * 1e-3)
+                                                       / 1e9 / (HBM_PEAK_GBS * world), 4)
+                    if n1 is not None:
+                        out['speedup_vs_n1'] = round(n_m.value / n1.value, 3)
+                    out['config']['collectives'] = ('RCCL C API from the C++ node, on the compute stream (checked against '
+                                                    'c10d at start-up); the same steps on torch.distributed\'s collectives '
+                                                    'are under "c10d"')
+                    out['c10d'] = c10d
+                else:
+                    out['native_collectives'] = native
+            else:
+                out['native_collectives'] = {'error': note}
+        if failed:  # the communicator may be unusable: no teardown
+            if out is not None:
+                out['launch'] = 'eager'
+            emit()
+            os._exit(0)
 
     # ---- the sharded step replayed from a HIP graph (N > 1; --shard-path on one GPU) -------------------------------------
     # One rank's shard of a strong split is a launch-bound step: ~120 us of kernels behind ~200 us of host time
