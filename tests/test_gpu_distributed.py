@@ -263,14 +263,14 @@ def test_native_collectives_equal_c10d(nccl_world1):
     x = torch.randn(8, 32, 28, 28, device=DEV, dtype=torch.bfloat16)
     g = torch.randn_like(x)
 
-    def run(group):
-        q = bench.build_quantizer(32, True, torch.device(DEV), group)
+    def run(group, per_channel=True):
+        q = bench.build_quantizer(32, per_channel, torch.device(DEV), group)
         xi = x.clone().requires_grad_(True)
         y, scale = q(xi)[:2]
         y.backward(g)
         return y.detach(), scale.detach(), xi.grad
 
-    plain = run(None)
+    plain, plain_t = run(None), run(None, False)
     c10d = run(nccl_world1)
     assert enable_native_collectives(nccl_world1) is True
     try:
@@ -278,6 +278,10 @@ def test_native_collectives_equal_c10d(nccl_world1):
         native = run(nccl_world1)
         for a, b, c, what in zip(plain, c10d, native, ('y', 'scale', 'dx')):
             assert torch.equal(a, b) and torch.equal(a, c), what
+        # a whole-tensor statistic: the forward's all-reduce is the direct call, the backward's bookkeeping stays on
+        # torch.distributed (the Python route) -- the two communicators side by side
+        for a, b, what in zip(plain_t, run(nccl_world1, False), ('y', 'scale', 'dx')):
+            assert torch.equal(a, b), ('per-tensor', what)
         job = bench.Job('act_pc', torch.bfloat16, torch.device(DEV), nccl_world1, 0, act_shape=(4, 64, 28, 28))
         elapsed, note = bench.graphed_run(job, steps=5, warmup=2, world=1, device=torch.device(DEV), group=nccl_world1)
         assert elapsed is not None and 'verified' in note, note
