@@ -781,9 +781,8 @@ def fast_stats_fakequant(x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste
 def fast_act_stats_fakequant(x, int_threshold, sp, qmin, qmax, round_mode, clamp_ste, pre_op, group, runtime):
     """The activation route of StatsFakeQuantFn (statistic kernel + quantizer kernel, the running statistic folded in,
     optionally batch-sharded with its two collectives) through the C++ node -> (y, scale, stat) with
-    `runtime.bvq_running_folded` set, or None: not a case it covers (channels_last / strided / unaligned input, a sharded
-    whole-tensor statistic, a running buffer that is not a plain [channels] device tensor, no extension built, timers
-    active)."""
+    `runtime.bvq_running_folded` set, or None: not a case it covers (channels_last / strided / unaligned input, a running
+    buffer that is not a plain [channels] device tensor, no extension built, timers active)."""
     mod = _fast_module()
     if not mod or not hasattr(mod, 'act_stats_fakequant') or not x.is_cuda or sp.nhwc or not x.is_contiguous() \
             or x.dtype not in _FLOATS or not config.FUSED_PATHS or x.numel() == 0:
@@ -793,7 +792,7 @@ def fast_act_stats_fakequant(x, int_threshold, sp, qmin, qmax, round_mode, clamp
         return None  # bench.py is bracketing the C-ABI calls of this step with HIP events: keep them visible
     if x.device.index is not None and x.device.index != torch.cuda.current_device():
         return None
-    if group is not None and (sp.channels <= 1 or not config.CPP_AUTOGRAD_SHARDED):
+    if group is not None and not config.CPP_AUTOGRAD_SHARDED:
         return None
     running = None
     momentum, first = 0.0, False

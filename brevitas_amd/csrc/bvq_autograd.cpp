@@ -13,7 +13,8 @@
 //                                            running average), bvq_fakequant_fwd
 //                                  backward  bvq_fakequant_bwd_stats[_onepass] (per-channel) |
 //                                            bvq_fakequant_bwd + bvq_stat_tie_apply_dscale (per-tensor)
-//     batch-sharded (brevitas_amd.distributed.shard_over_batch, per-channel):
+//     batch-sharded (brevitas_amd.distributed.shard_over_batch; a whole-tensor statistic: bvq_fakequant_bwd, bvq_shard_pack,
+//     all-gather of [dscale sum | tie count], bvq_shard_unpack, bvq_stat_tie_apply_dscale over the ties of all shards):
 //                                  forward   float32 statistic, all-reduce(MAX), bvq_scale_from_stat_running,
 //                                            bvq_fakequant_fwd
 //                                  backward  bvq_fakequant_bwd_shard, all-gather, bvq_shard_unpack_deposit
@@ -26,7 +27,7 @@
 // The C-ABI entries are the ones the Python route calls (include/bvq.h, included here: the descriptor layout and every
 // prototype come from that header), resolved with dlsym from the library the package has already loaded and checked
 // against BVQ_ABI_VERSION; no HIP header is needed.  Anything a node does not cover (a gradient arriving through
-// `scale`, an unaligned or non-contiguous gradient, a sharded per-tensor statistic) goes back to the Python
+// `scale`, an unaligned or non-contiguous gradient) goes back to the Python
 // implementation through the fallback registered at start-up.  Reference boundary: proxy.tensor_quant(x),
 // B/proxy/parameter_quant.py:83-89 and B/proxy/runtime_quant.py:80-84 -> RescalingIntQuant.forward,
 // B/core/quant/int.py:155-163.
@@ -68,7 +69,9 @@ namespace {
   X(bvq_tie_info_bytes)                      \
   X(bvq_stat_tie_apply_dscale)               \
   X(bvq_fakequant_bwd_shard)                 \
-  X(bvq_shard_unpack_deposit)
+  X(bvq_shard_unpack_deposit)                \
+  X(bvq_shard_pack)                          \
+  X(bvq_shard_unpack)
 #define BVQ_DECLARE(name) decltype(&name) p_##name = nullptr;
 BVQ_ENTRIES(BVQ_DECLARE)
 #undef BVQ_DECLARE
@@ -375,7 +378,7 @@ class ActStatsFakeQuant : public torch::autograd::Function<ActStatsFakeQuant> {
       py_group = ref.py;
     }
     const bool per_channel = d.channels > 1;
-    if (!direct_gradient(gy, gscale, x) || (group && !per_channel)) {
+    if (!direct_gradient(gy, gscale, x)) {
       return python_backward(ctx, gy, gscale, py_group, 6);
     }
     void* st = reinterpret_cast<void*>(dv[16]);
@@ -434,10 +437,33 @@ class ActStatsFakeQuant : public torch::autograd::Function<ActStatsFakeQuant> {
                                 ds.data_ptr<float>(), nullptr, stat.data_ptr(), info.data_ptr<int64_t>(), ws.data_ptr(), ws.numel(),
                                 st),
             "bvq_fakequant_bwd");
+      const int64_t* total_ties = nullptr;
+      at::Tensor total;
+      if (group) {
+        // batch shard: the shards' dscale sums are added (double, rank order: the same bits on every rank) and the ties
+        // of the whole batch share the statistic's gradient evenly -- one all-gather of [dscale sum | tie count]
+        const int rank = group->getRank(), world = group->getSize();
+        at::Tensor msg = at::empty({2}, x.options().dtype(at::kDouble));
+        check(p_bvq_shard_pack(ds.data_ptr<float>(), info.data_ptr<int64_t>(), 1, rank, 0, msg.data_ptr<double>(), st),
+              "bvq_shard_pack");
+        at::Tensor gathered = at::empty({world * msg.numel()}, msg.options());
+        if (const NativeComm* nc = native_comm(group->getGroupName())) {
+          rccl_check(rccl().all_gather(msg.data_ptr<double>(), gathered.data_ptr<double>(), (size_t)msg.numel(),
+                                       ncclFloat64, nc->comm, reinterpret_cast<hipStream_t>(st)),
+                     "ncclAllGather");
+        } else {
+          group->_allgather_base(gathered, msg)->wait();
+        }
+        total = at::empty({1}, x.options().dtype(at::kLong));
+        check(p_bvq_shard_unpack(gathered.data_ptr<double>(), world, 1, rank, 0, ds.data_ptr<float>(),
+                                 info.data_ptr<int64_t>(), total.data_ptr<int64_t>(), st),
+              "bvq_shard_unpack");
+        total_ties = total.data_ptr<int64_t>();
+      }
       // (qr[3]: the threshold the quotient dscale / int_threshold is divided by; dv[17]: its dtype)
       check(p_bvq_stat_tie_apply_dscale(d.pre_op, d.x_dtype, x.data_ptr(), stat.data_ptr(), ds.data_ptr<float>(), sdt,
-                                        qr[2], (int)dv[17], info.data_ptr<int64_t>(), nullptr, dx.data_ptr(), d.outer, d.channels,
-                                        d.inner, st),
+                                        qr[2], (int)dv[17], info.data_ptr<int64_t>(), total_ties, dx.data_ptr(), d.outer,
+                                        d.channels, d.inner, st),
             "bvq_stat_tie_apply_dscale");
     }
     out[0] = dx;
@@ -513,7 +539,6 @@ py::object act_stats_fakequant(const at::Tensor& x, const at::Tensor& zp, const 
   const bool per_channel = p.d.channels > 1;
   if (per_channel && p_bvq_fakequant_bwd_stats_workspace_bytes(&p.d) <= 0) return py::none();
   if (!group.is_none()) {
-    if (!per_channel) return py::none();  // sharded whole-tensor statistics keep the Python route (tie counts over shards)
     p.group = group.cast<c10::intrusive_ptr<c10d::ProcessGroup>>();
     p.py_group = group;
   }

@@ -148,15 +148,15 @@ def test_cpp_activation_node_sharded_world_of_one(monkeypatch):
     sock.close()
     torch.cuda.set_device(0)
     # twice: the second default group has the first one's name and another communicator -- the node must follow it
-    for _ in range(2):
+    for per_channel in (True, False):
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
         try:
-            _sharded_world_of_one(monkeypatch, dist, build_quantizer, _fused)
+            _sharded_world_of_one(monkeypatch, dist, build_quantizer, _fused, per_channel)
         finally:
             dist.destroy_process_group()
 
 
-def _sharded_world_of_one(monkeypatch, dist, build_quantizer, _fused):
+def _sharded_world_of_one(monkeypatch, dist, build_quantizer, _fused, per_channel=True):
     torch.manual_seed(5)
     x = torch.randn(8, 32, 28, 28, device=DEV, dtype=torch.bfloat16)
     g = torch.randn_like(x)
@@ -168,9 +168,18 @@ def _sharded_world_of_one(monkeypatch, dist, build_quantizer, _fused):
         calls['n'] += r is not None
         return r
     monkeypatch.setattr(_fused, 'fast_act_stats_fakequant', counted)
-    sharded = _act_steps(build_quantizer(32, True, torch.device(DEV), dist.group.WORLD), x, g, 2, [dict()])
-    plain = _act_steps(build_quantizer(32, True, torch.device(DEV)), x, g, 2, [dict()])
+    x[1, 3, 2, 2] = 9.0
+    x[5, 7, 1, 1] = -9.0   # two ties of the whole-tensor maximum: they share its gradient
+    sharded = _act_steps(build_quantizer(32, per_channel, torch.device(DEV), dist.group.WORLD), x, g, 2, [dict()])
+    plain = _act_steps(build_quantizer(32, per_channel, torch.device(DEV)), x, g, 2, [dict()])
     assert calls['n'] == 4
+    # the Python Function on the same sharded quantizer (the node switched off): the same bits
+    monkeypatch.setattr(_fused, 'fast_act_stats_fakequant', lambda *a, **k: None)
+    python = _act_steps(build_quantizer(32, per_channel, torch.device(DEV), dist.group.WORLD), x, g, 2, [dict()])
+    monkeypatch.setattr(_fused, 'fast_act_stats_fakequant', counted)
+    for a, b in zip(sharded, python):
+        for ta, tb, what in zip(a, b, ('y', 'scale', 'dx', 'running')):
+            assert torch.equal(_bits(ta), _bits(tb)), ('node vs Python Function', what)
     for a, b in zip(sharded, plain):
         for ta, tb, what in zip(a, b, ('y', 'scale', 'dx', 'running')):
             assert torch.equal(_bits(ta), _bits(tb)), what
