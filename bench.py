@@ -9,12 +9,16 @@ scale = max(stat, 1e-10)/128, quantize-dequantize; RescalingIntQuant with Runtim
 training mode) followed by its full autograd backward (clamp mask, scale-gradient
 reduction, deposit on the arg-max elements).  Nothing is skipped or cached between steps.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the batch is sharded over the ranks and the
-only exchanges are the all-reduce of the scale statistic (RCCL, <= 4 KB) in forward and the all-gather of
-the scale-gradient sums in backward (brevitas_amd.distributed).  The judged line is WEAK scaling (every
-rank holds its own [256,512,56,56] shard; value = elements quantized by all ranks / max-over-ranks time);
-the same run also times the STRONG-scaled split SURVEY 8e names (a global [256,512,56,56] cut into
-256/N rows per rank) and reports it under "strong".
+N > 1 (one rank per GPU: started bare, this script launches torch.distributed.run itself as a child process before it
+touches the GPU; under torch.distributed.run it is a rank): the batch is sharded over the ranks and the only exchanges
+are the all-reduce of the scale statistic (RCCL, <= 4 KB) in forward and the all-gather of the scale-gradient sums in
+backward (brevitas_amd.distributed).  The judged line is STRONG scaling, the split SURVEY 8e names: the global
+[256,512,56,56] cut into 256/N rows per rank, value = elements quantized by all ranks / max-over-ranks time.  The same
+run and line also hold "n1" (rank 0 alone on the whole tensor, before the sharded job starts), "speedup_vs_n1" and
+"weak" (every rank its own whole tensor).  All of that is measured on torch.distributed's collectives; then the group
+gets a communicator on RCCL's C API (checked against torch.distributed on every rank, under a watchdog) and the strong
+split runs once more with the C++ autograd node issuing its two collectives directly on the compute stream -- the line
+takes the faster of the two and names it (config.collectives).  --graph (opt-in) also replays the step from a HIP graph.
 
 Other workloads (--workload): the remaining BASELINE.json configs, same JSON shape --
   weight_conv_int8    config 2: Int8WeightPerChannelFloat on a [512,512,3,3] conv weight (us per step; eager and
