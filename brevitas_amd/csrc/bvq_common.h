@@ -326,8 +326,14 @@ struct ColsPlan {
 #endif
 constexpr int kColsTeamVec16 = BVQ_COLS_TEAM_VEC16;
 // team: the caller's kernel gives a unit to a whole workgroup (four waves sharing the rows, partials combined on chip)
+// vec16: columns of a 16-bit type per lane (0: 8, one 16-byte load per row -- or kColsTeamVec16 for team units)
 ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bool no_partials = false,
-                   bool team = false);
+                   bool team = false, int vec16 = 0);
+// columns of a 16-bit type a lane of the column-mapped FORWARD holds
+#ifndef BVQ_COLS_FWD_VEC16
+#define BVQ_COLS_FWD_VEC16 4
+#endif
+constexpr int kColsFwdVec16 = BVQ_COLS_FWD_VEC16;
 
 static inline unsigned grid_for_units(int64_t units) {
   return (unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock);

@@ -128,12 +128,12 @@ int env_flag(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bool no_partials, bool team) {
+ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bool no_partials, bool team, int vec16) {
   static const int enabled = env_flag("BVQ_COLS", 1);
   ColsPlan p = {};
   const int el = dtype == BVQ_F32 ? 4 : 2;
   // (the backward's workgroup units hold kColsTeamVec16 columns of a 16-bit type per lane: bvq_common.h)
-  const int vec = team && el == 2 ? kColsTeamVec16 : 16 / el;
+  const int vec = el == 2 ? (vec16 > 0 ? vec16 : (team ? kColsTeamVec16 : 8)) : 4;
   // short inner runs: from 256 bytes per channel row on, the row-mapped units stream well -- unless the rows are
   // not 16-byte multiples (14x14 maps of a 16-bit type: 392 bytes), where the row-mapped route drops to 8- or
   // 2-byte accesses: [1024,1024,14,14] bf16 forward 3.0 -> 5.5 TB/s, abs-max 3.3 -> 5.1 on this route
@@ -169,6 +169,13 @@ ColsPlan cols_plan(int dtype, int64_t outer, int64_t channels, int64_t inner, bo
   const int64_t want_blocks = want_units / p.strips > 0 ? want_units / p.strips : 1;
   const int64_t rows_for_that = (outer + want_blocks - 1) / want_blocks;
   if (rows_for_that > rb) rb = ((rows_for_that + p.rpp - 1) / p.rpp) * p.rpp;
+  if (no_partials && !team && !env_units) {
+    // the forward (no partial rows): short blocks by row count -- the resident waves' window of memory again -- and
+    // not a power of two (8 / 12 / 16 / 24 rows: [802816,512] float32 0.583 / 0.569 / 0.615 / 0.605 ms, [65536,4096]
+    // bf16 0.183 / 0.180 / 0.196 / 0.195; it was 25..98 rows: 0.617 and 0.200 -- profiles/r03_column_mapped.txt)
+    static const int env_frows = env_flag("BVQ_COLS_FWD_ROWS", 0);  // experiments only
+    rb = (env_frows > 0 ? env_frows : 12) * (int64_t)p.rpp;
+  }
   if (team && !no_partials && !env_units) {
     // a workgroup's rows by count, not by a unit total: short blocks keep the resident workgroups' window of memory
     // small, which is what these kernels' bandwidth follows (profiles/r03_column_mapped.txt) -- down to where a wave's

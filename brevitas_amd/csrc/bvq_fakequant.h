@@ -370,13 +370,13 @@ static void fill_args(QuantArgs& a, const bvq_quant_desc* d) {
 
 // column-mapped route for this call? (channel axis last or nearly last; see ColsPlan)
 static ColsPlan cols_quant_plan(const bvq_quant_desc* d, const void* p0, const void* p1, const void* p2,
-                                bool no_partials = false, bool team = false) {
+                                bool no_partials = false, bool team = false, int vec16 = 0) {
   ColsPlan none = {};
   if (!(d->scale_per_channel && d->channels > 1) || d->x_dtype != d->ct_dtype || d->out_kind != BVQ_OUT_DEQUANT)
     return none;
   if ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15)
     return none;
-  return cols_plan(d->x_dtype, d->outer, d->channels, d->inner, no_partials, team);
+  return cols_plan(d->x_dtype, d->outer, d->channels, d->inner, no_partials, team, vec16);
 }
 
 static void fill_cols_args(ColsQuantArgs& a, const ColsPlan& cp, const bvq_quant_desc* d) {

@@ -186,36 +186,45 @@ __global__ __launch_bounds__(kBlock) void fakequant_fwd_kernel(QuantArgs a) {
 }
 
 
-template <typename T, int RM, bool NT, bool ZP0, bool FAST>
-__device__ __forceinline__ void cols_fwd_rows(const ColsQuantArgs& a, const ColsLane<T>& ln, float qmin, float qmax) {
-  constexpr int VEC = elem<T>::vec;
+template <typename T>
+constexpr int kColsFwdVec = sizeof(T) == 2 ? kColsFwdVec16 : elem<T>::vec;
+
+// One wave's unit of the column-mapped forward: a block of rows of its strip of 64 column chunks, addressed through buffer
+// descriptors like the backward's (bvq_fakequant_bwd.h, cols_bwd_rows): rows past the block's end read zeros without a
+// memory access and drop their stores, so the walk has no execution mask and no 64-bit address arithmetic; the fused ReLU
+// is a template parameter; a lane holds 4 columns of a 16-bit type (8-byte loads: half the per-column scales /
+// reciprocals / zero-points to fetch and divide at the start of every unit, half the registers).
+template <typename T, int RM, bool NT, bool ZP0, bool FAST, bool PRE>
+__device__ __forceinline__ void cols_fwd_rows(const ColsQuantArgs& a, const ColsLane<T, kColsFwdVec<T>>& ln, float qmin,
+                                              float qmax) {
+  constexpr int VEC = kColsFwdVec<T>;
 #ifndef BVQ_COLS_FWD_UNROLL
 #define BVQ_COLS_FWD_UNROLL 4  // rows in flight per lane
 #endif
   constexpr int kU = BVQ_COLS_FWD_UNROLL;
-  const T* __restrict__ xp = reinterpret_cast<const T*>(a.x) + (int64_t)ln.chunk * VEC;
-  T* __restrict__ yp = reinterpret_cast<T*>(a.y) + (int64_t)ln.chunk * VEC;
+  const int64_t nrows = ln.row_end - ln.blk0;  // wave-uniform, > 0
+  const uint32_t bytes = (uint32_t)(nrows * a.p.L * (int64_t)sizeof(T));
+  const buf_t bx = make_buf(reinterpret_cast<const T*>(a.x) + ln.blk0 * a.p.L, bytes);
+  const buf_t by = make_buf(reinterpret_cast<T*>(a.y) + ln.blk0 * a.p.L, bytes);
+  const uint32_t step = (uint32_t)((int64_t)a.p.rpp * a.p.L * (int64_t)sizeof(T));  // between a lane's consecutive rows
+  uint32_t off = (uint32_t)(((int64_t)ln.sub * a.p.L + (int64_t)ln.chunk * VEC) * (int64_t)sizeof(T));
+  const int32_t steps = (int32_t)((nrows + a.p.rpp - 1) / a.p.rpp);  // rows per lane, the last possibly past the end
   f2 r2[VEC / 2];
 #pragma unroll
   for (int k = 0; k < VEC / 2; ++k) r2[k] = f2{1.0f / ln.s2[k].x, 1.0f / ln.s2[k].y};
   const int mode = a.round_mode;
-  for (int64_t r = ln.row0; r < ln.row_end; r += (int64_t)kU * a.p.rpp) {
+  for (int32_t i = 0; i < steps; i += kU) {
     vec_t<T, VEC> xv[kU];
-    bool ok[kU];
+#pragma unroll
+    for (int j = 0; j < kU; ++j) xv[j] = buf_load<T, VEC, NT>(bx, off + (uint32_t)j * step);
 #pragma unroll
     for (int j = 0; j < kU; ++j) {
-      const int64_t rr = r + (int64_t)j * a.p.rpp;
-      ok[j] = rr < ln.row_end;
-      xv[j] = load_vec<T, VEC, NT>(xp + (ok[j] ? rr : ln.row0) * a.p.L);
-    }
-#pragma unroll
-    for (int j = 0; j < kU; ++j) {
-      if (ok[j]) {
+      if (i + j < steps) {  // wave-uniform
         vec_t<T, VEC> yv;
 #pragma unroll
         for (int k = 0; k < VEC; k += 2) {
           f2 xf = widen2<T>(xv[j].v[k], xv[j].v[k + 1]);
-          if (a.pre_relu) xf = relu2(xf);
+          if constexpr (PRE) xf = relu2(xf);
           f2 q2, res;
           if constexpr (FAST && elem<T>::id == BVQ_F16)
             res = fwd_elem2<T, RM, ZP0>(xf, BVQ_DIVF16V{ln.s2[k / 2], r2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax, false,
@@ -226,33 +235,40 @@ __device__ __forceinline__ void cols_fwd_rows(const ColsQuantArgs& a, const Cols
             res = fwd_elem2<T, RM, ZP0>(xf, DivExactV{ln.s2[k / 2]}, ln.s2[k / 2], ln.z2[k / 2], qmin, qmax, false, mode, q2);
           pack2<T>(res, yv.v[k], yv.v[k + 1]);
         }
-        store_vec<T, VEC, NT>(yp + (r + (int64_t)j * a.p.rpp) * a.p.L, yv);
+        buf_store<T, VEC, NT>(by, off + (uint32_t)j * step, yv);  // dropped past the block's end
       }
     }
+    off += (uint32_t)kU * step;
   }
 }
 
 template <typename T, int RM, bool NT>
 __global__ __launch_bounds__(kBlock) void fakequant_fwd_cols_kernel(ColsQuantArgs a) {
-  ColsLane<T> ln;
+  ColsLane<T, kColsFwdVec<T>> ln;
   if (!ln.init(a) || !ln.active) return;
   const float qmin = rnd<T>(a.qmin), qmax = rnd<T>(a.qmax);
+#define BVQ_COLS_FWD(ZP0, FAST)                                \
+  do {                                                         \
+    if (a.pre_relu)                                            \
+      cols_fwd_rows<T, RM, NT, ZP0, FAST, true>(a, ln, qmin, qmax);  \
+    else                                                       \
+      cols_fwd_rows<T, RM, NT, ZP0, FAST, false>(a, ln, qmin, qmax); \
+  } while (0)
   if constexpr (sizeof(T) == 2) {
     if (ln.fast) {
       if (ln.zp0)
-        cols_fwd_rows<T, RM, NT, true, true>(a, ln, qmin, qmax);
+        BVQ_COLS_FWD(true, true);
       else
-        cols_fwd_rows<T, RM, NT, false, true>(a, ln, qmin, qmax);
+        BVQ_COLS_FWD(false, true);
       return;
     }
-  }
-  if constexpr (sizeof(T) == 2) {
     if (ln.zp0) {
-      cols_fwd_rows<T, RM, NT, true, false>(a, ln, qmin, qmax);
+      BVQ_COLS_FWD(true, false);
       return;
     }
   }
-  cols_fwd_rows<T, RM, NT, false, false>(a, ln, qmin, qmax);
+  BVQ_COLS_FWD(false, false);
+#undef BVQ_COLS_FWD
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -466,7 +482,7 @@ static int fakequant_fwd_impl(const bvq_quant_desc* d, const void* x, const void
     return BVQ_ERR_INVALID;
   }
   if (y && !codes && !bounds) {
-    const ColsPlan cp = cols_quant_plan(d, x, y, nullptr, true);
+    const ColsPlan cp = cols_quant_plan(d, x, y, nullptr, true, false, kColsFwdVec16);
     if (cp.ok) {
       ColsQuantArgs ca = {};
       fill_cols_args(ca, cp, d);
