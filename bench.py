@@ -403,6 +403,7 @@ def parse_args(argv=None):
                     help='N > 1 (or --shard-path): also measure the step replayed from a HIP graph and report the faster '
                          'of the two.  Off by default: multi-rank RCCL inside a captured graph has not run on this '
                          'pool, and a process that dies inside the capture prints nothing')
+    ap.add_argument('--die-in-late-phase', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--native-timeout', type=float, default=120.0,
                     help='N > 1: seconds the re-run on direct RCCL calls may take before the line is printed without it')
     ap.add_argument('--graph-timeout', type=float, default=120.0,
@@ -417,6 +418,43 @@ def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(('127.0.0.1', 0))
         return s.getsockname()[1]
+
+
+class LineGuard:
+    """N > 1, rank 0: a forked helper (before this process touches the GPU; it runs nothing but read / write / _exit)
+    that holds the result descriptor and the read end of a pipe.  Rank 0 hands it the line as it stands before every
+    late, optional phase (the re-run on direct RCCL calls, the HIP graph) and tells it when the final line is out.  If
+    rank 0's end of the pipe closes without that word -- the process died inside such a phase -- the helper prints the
+    last line it was handed: the measurements that were complete are not lost with the process."""
+
+    def __init__(self, fd):
+        r, w = os.pipe()
+        if os.fork() == 0:
+            try:
+                os.close(w)
+                buf = b''
+                while True:
+                    chunk = os.read(r, 65536)
+                    if not chunk:
+                        break
+                    buf += chunk
+                msgs = buf.split(b'\n')
+                lines = [m for m in msgs if m.startswith(b'{')]
+                if b'FINAL' not in msgs and lines:
+                    os.write(fd, lines[-1] + b'\n')
+            finally:
+                os._exit(0)
+        os.close(r)
+        self.w = w
+
+    def provisional(self, out, phase):
+        d = dict(out)
+        d['late_phase'] = ('the process ended inside the %s phase; everything in this line was measured before it' % phase)
+        d.setdefault('launch', 'eager')
+        os.write(self.w, (json.dumps(d) + '\n').encode())
+
+    def final(self):
+        os.write(self.w, b'FINAL\n')
 
 
 def launch_workers(args, argv):
@@ -450,6 +488,11 @@ def launch_workers(args, argv):
     lines = [ln for ln in out.decode(errors='replace').splitlines() if ln.startswith('{') and '"metric"' in ln]
     if proc.returncode != 0:
         sys.stderr.write('bench.py: torch.distributed.run exited with status %d\n' % proc.returncode)
+        if len(lines) == 1 and '"late_phase"' in lines[0]:
+            # rank 0 died inside a late, optional phase: its helper has printed the line of the completed measurements
+            sys.stdout.write(lines[0] + '\n')
+            sys.stdout.flush()
+            return 0
         return proc.returncode or 1
     if len(lines) != 1:
         sys.stderr.write('bench.py: expected one JSON line from rank 0, got %d\n' % len(lines))
@@ -544,6 +587,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    guard = LineGuard(result_fd) if world > 1 and rank == 0 else None   # (forks: before anything touches the GPU)
     kind, dtype, descr = WORKLOADS[args.workload]
     on_gpu = args.device == 'cuda'
     full_shape = tuple(int(v) for v in args.act_shape.split(',')) if args.act_shape else None
@@ -765,6 +809,14 @@ def main():
                 emitted.append(True)
                 sys.stdout.flush()
                 os.write(result_fd, (json.dumps(out) + '\n').encode())
+                if guard is not None:
+                    guard.final()
+
+    if args.die_in_late_phase and world > 1:   # test hook (tests/test_bench_launcher.py): a rank 0 that dies after its
+        if guard is not None:                  # measurements are complete leaves its line behind through the helper
+            guard.provisional(out, 'test')
+            os.abort()
+        time.sleep(5.0)                        # (the other ranks: torch.distributed.run ends them)
 
     # ---- N > 1: the strong split once more with the two collectives as direct RCCL calls -----------------------------------
     # Everything above ran on torch.distributed's collectives and is complete.  Now the group gets a communicator of its
@@ -780,6 +832,8 @@ def main():
                 out['launch'] = 'eager'
             emit()
             os._exit(0)
+        if guard is not None:
+            guard.provisional(out, 'direct-RCCL-collectives')
         watchdog = threading.Timer(args.native_timeout, abandon_native)
         watchdog.daemon = True
         watchdog.start()
@@ -837,6 +891,8 @@ def main():
                 out['launch'] = 'eager'
             emit()
             os._exit(0)
+        if guard is not None:
+            guard.provisional(out, 'HIP-graph')
         watchdog = threading.Timer(args.graph_timeout, abandon)
         watchdog.daemon = True
         watchdog.start()

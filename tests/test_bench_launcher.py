@@ -49,3 +49,17 @@ def test_the_launcher_kills_workers_that_do_not_finish():
                '8,16,7,7', '--launch-timeout', '0.2')
     assert r.returncode == 124
     assert not r.stdout.strip()
+
+
+def test_a_rank_0_that_dies_in_a_late_phase_leaves_its_line_behind():
+    """before every late, optional phase (direct RCCL calls, HIP graph) rank 0 hands the line as it stands to a helper it
+    forked before touching the GPU; if the process then dies, the helper prints that line -- marked -- and the launcher
+    passes it on (--die-in-late-phase: rank 0 aborts right after handing its complete measurements over)"""
+    r = _bench('--gpus', '2', '--steps', '3', '--warmup', '1', '--backend', 'gloo', '--device', 'cpu', '--act-shape',
+               '8,16,7,7', '--die-in-late-phase')
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert 'late_phase' in out and out['n_gpus'] == 2 and out['scaling'] == 'strong'
+    assert out['n1']['tensors_per_gpu'] == [[8, 16, 7, 7]] and out['weak']['scaling'] == 'weak'
