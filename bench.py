@@ -18,7 +18,9 @@ run and line also hold "n1" (rank 0 alone on the whole tensor, before the sharde
 "weak" (every rank its own whole tensor).  All of that is measured on torch.distributed's collectives; then the group
 gets a communicator on RCCL's C API (checked against torch.distributed on every rank, under a watchdog) and the strong
 split runs once more with the C++ autograd node issuing its two collectives directly on the compute stream -- the line
-takes the faster of the two and names it (config.collectives).  --graph (opt-in) also replays the step from a HIP graph.
+takes the faster of the two and names it (config.collectives); last, the step is captured into a HIP graph (kernels and
+the two direct RCCL calls), checked bit for bit against the eager step and replayed ("launch", "eager", "hipgraph").
+Each late phase runs under a watchdog and after the line so far has been handed to a helper process (LineGuard).
 
 Other workloads (--workload): the remaining BASELINE.json configs, same JSON shape --
   weight_conv_int8    config 2: Int8WeightPerChannelFloat on a [512,512,3,3] conv weight (us per step; eager and
@@ -400,9 +402,10 @@ def parse_args(argv=None):
                     help='N > 1: keep the sharded step\'s collectives on torch.distributed (default: RCCL\'s C API from the '
                          'C++ node when its start-up check against c10d passes)')
     ap.add_argument('--graph', action='store_true',
-                    help='N > 1 (or --shard-path): also measure the step replayed from a HIP graph and report the faster '
-                         'of the two.  Off by default: multi-rank RCCL inside a captured graph has not run on this '
-                         'pool, and a process that dies inside the capture prints nothing')
+                    help='--shard-path on one GPU: also measure the step replayed from a HIP graph and report the faster of '
+                         'the two (N > 1 does so by default once the direct RCCL calls are in use)')
+    ap.add_argument('--no-graph', action='store_true',
+                    help='N > 1: do not measure the step replayed from a HIP graph')
     ap.add_argument('--die-in-late-phase', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--native-timeout', type=float, default=120.0,
                     help='N > 1: seconds the re-run on direct RCCL calls may take before the line is printed without it')
@@ -882,9 +885,11 @@ def main():
     # (profiles/r03_strong_scaling.md).  Captured once -- kernels, the all-reduce and the all-gather alike -- and
     # replayed, the host leaves the critical path.  Everything above is measured eagerly and is complete at this point:
     # if the capture raises, the replay does not reproduce the eager gradients, or nothing comes back within
-    # --graph-timeout seconds, the eager line is printed as it stands.  Opt-in (--graph): a process that DIES inside a
-    # capture with N ranks of RCCL -- never run on this one-GPU-per-box pool -- would print nothing at all.
-    if on_gpu and group is not None and has_act and scaling == 'strong' and args.graph:
+    # --graph-timeout seconds, the eager line is printed as it stands; if the process dies inside the capture -- N ranks
+    # of RCCL in a captured graph have never run on this one-GPU-per-box pool -- rank 0's helper prints it (LineGuard).
+    # Only direct RCCL calls are ever captured (graphed_run).
+    if on_gpu and group is not None and has_act and scaling == 'strong' and native_coll \
+            and (args.graph or (world > 1 and not args.no_graph)):
         def abandon():
             if out is not None:
                 out['hipgraph'] = {'error': 'no result within %g s: abandoned, the eager measurement stands' % args.graph_timeout}
